@@ -1,0 +1,474 @@
+"""CPU oracle for the MEANT encoder hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (fp32, CPU, autograd) restatement of the arithmetic of
+biirving/meant's multimodal encoder forward pass.  It exists so that the hand-written
+HIP path in ``meant_amd/`` has something independent to be checked against on a GPU
+box where the reference itself is not present.
+
+Rules (enforced by tests/test_layout.py):
+  * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+    may import this module;  nothing under ``meant_amd/`` does;
+  * it is never the thing that is measured as the product and never a fallback.
+
+Pinning: every class below is checked (tests/test_oracle_golden.py) against golden
+vectors that ``oracle/gen_golden.py`` produced by importing the reference's own
+modules from /root/reference in the build container (fixtures in tests/golden/).
+Parity vs the vendored ``meant/rotary_embedding_torch.py`` is therefore pinned;
+parity vs pip ``rotary-embedding-torch==0.5.3`` (not in the tree) is unpinned.
+
+Every function cites the reference file:line whose behaviour it restates.  The code
+is written from the formulas, not transcribed: no einops, no
+rotary library, explicit index arithmetic.  ``state_dict`` keys match the reference
+so one set of weights drives the reference, the oracle and the HIP modules.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# a1  RMSNorm                                         reference: utils/rms_norm.py:17-57
+# --------------------------------------------------------------------------------------
+class RMSNorm(nn.Module):
+    """y = scale * x / (||x||_2 / sqrt(d) + eps); eps is added to the RMS, outside the
+    square root (utils/rms_norm.py:52-53).  Only the p<0, bias=False form is on the
+    hot path (utils/rms_norm.py:41-43,57)."""
+
+    def __init__(self, d: int, eps: float = 1e-8):
+        super().__init__()
+        self.d = d
+        self.eps = eps
+        self.scale = nn.Parameter(torch.ones(d))
+
+    def forward(self, x):
+        l2 = torch.sqrt(torch.sum(x * x, dim=-1, keepdim=True))
+        rms = l2 * (self.d ** -0.5)
+        return self.scale * (x / (rms + self.eps))
+
+
+# --------------------------------------------------------------------------------------
+# a2-a5  rotary / xPos tables        reference: meant/rotary_embedding_torch.py:58-147
+# --------------------------------------------------------------------------------------
+class RotaryTable(nn.Module):
+    """Holds ``freqs`` (a frozen Parameter, :85) and, for xPos, the ``scale`` buffer
+    (:90-92) under the reference's state_dict names."""
+
+    def __init__(self, dim: int, kind: str, use_xpos: bool = False,
+                 theta: float = 10000.0, max_freq: float = 10.0, scale_base: float = 512.0):
+        super().__init__()
+        half = dim // 2
+        if kind == "lang":      # :75   theta^-(2j/dim)
+            j2 = torch.arange(0, dim, 2)[:half].float()
+            freqs = 1.0 / (theta ** (j2 / dim))
+        elif kind == "pixel":   # :77   pi * linspace(1, max_freq/2, dim//2)
+            freqs = torch.linspace(1.0, max_freq / 2, half) * math.pi
+        else:
+            raise ValueError(kind)
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+        self.use_xpos = use_xpos
+        self.scale_base = scale_base
+        if use_xpos:            # :90-92
+            self.register_buffer("scale", (torch.arange(0, dim, 2) + 0.4 * dim) / (1.4 * dim))
+        else:
+            self.scale = None
+
+    @property
+    def rot_dim(self) -> int:
+        return 2 * self.freqs.numel()
+
+    def cos_sin(self, seq_len: int):
+        """(S, rot_dim) cos / sin with each frequency repeated on two adjacent lanes
+        (:140-142); angles are formed in fp32 (:141)."""
+        pos = torch.arange(seq_len, device=self.freqs.device).to(self.freqs.dtype)
+        ang = pos[:, None] * self.freqs[None, :]                  # (S, R/2)
+        ang = torch.repeat_interleave(ang, 2, dim=-1)             # lanes (2j, 2j+1) share j
+        return ang.cos(), ang.sin()
+
+    def xpos_scale(self, seq_len: int):
+        """(S, rot_dim) zeta^((pos - S//2)/scale_base), laid out as two concatenated
+        blocks, i.e. lane c uses zeta[c mod R/2] (:121-125) -- not interleaved."""
+        pos = torch.arange(seq_len, device=self.freqs.device)
+        power = (pos - seq_len // 2) / self.scale_base
+        s = self.scale[None, :] ** power[:, None]                 # (S, R/2)
+        return torch.cat((s, s), dim=-1)
+
+
+def rotate_pairs(t, cos, sin, scale=None):
+    """apply_rotary_emb + rotate_half (:31-44): on lanes [0, R) of the last axis,
+    out[2j] = t[2j] c - t[2j+1] s ; out[2j+1] = t[2j+1] c + t[2j] s (times scale);
+    lanes >= R pass through untouched."""
+    R = cos.shape[-1]
+    head, tail = t[..., :R], t[..., R:]
+    even, odd = head[..., 0::2], head[..., 1::2]
+    swapped = torch.stack((-odd, even), dim=-1).reshape(head.shape)
+    if scale is None:
+        out = head * cos + swapped * sin
+    else:
+        out = head * cos * scale + swapped * sin * scale
+    return torch.cat((out, tail), dim=-1)
+
+
+def _split_heads(x, h):
+    b, s, d = x.shape
+    return x.view(b, s, h, d // h).permute(0, 2, 1, 3)            # b h s dh
+
+
+def _merge_heads(x):
+    b, h, s, dh = x.shape
+    return x.permute(0, 2, 1, 3).reshape(b, s, h * dh)
+
+
+# --------------------------------------------------------------------------------------
+# a6  spatial attention over patches                 reference: meant/attention.py:14-62
+# --------------------------------------------------------------------------------------
+class attention(nn.Module):
+    """K comes from the Linear called ``v`` and V from the one called ``k`` (:36-37);
+    the scale is 1/sqrt(Dh*H) = 1/sqrt(dim) (:43); pixel rotary on q and k with raster
+    positions 0..N-1 (:39-40); never masked."""
+
+    def __init__(self, num_heads: int, dim: int, pos_emb: RotaryTable):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        self.Dh = dim // num_heads
+        self.pos_emb = pos_emb
+        self.multi_mad = nn.Linear(self.num_heads * self.Dh, dim)
+        self.q = nn.Linear(dim, self.Dh * num_heads)
+        self.v = nn.Linear(dim, self.Dh * num_heads)
+        self.k = nn.Linear(dim, self.Dh * num_heads)
+
+    def forward(self, x):
+        H = self.num_heads
+        q, k, v = _split_heads(self.q(x), H), _split_heads(self.v(x), H), _split_heads(self.k(x), H)
+        cos, sin = self.pos_emb.cos_sin(x.shape[1])
+        q, k = rotate_pairs(q, cos, sin), rotate_pairs(k, cos, sin)
+        scores = (q @ k.transpose(-1, -2)) / math.sqrt(self.Dh * H)
+        w = torch.softmax(scores, dim=-1)
+        return self.multi_mad(_merge_heads(w @ v))
+
+
+# --------------------------------------------------------------------------------------
+# a7  causal xPos text attention                 reference: meant/xPosAttention.py:13-66
+# --------------------------------------------------------------------------------------
+class xPosAttention(nn.Module):
+    """As ``attention`` with xPos rotation (q * zeta^p, k * zeta^-p, :39), an
+    always-on causal -inf mask (:43-50) and an additive (1-mask)*-1e9 key padding
+    term (:54-56)."""
+
+    def __init__(self, num_heads: int, dim: int, xPos: RotaryTable):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        self.Dh = dim // num_heads
+        self.xPos = xPos
+        self.multi_mad = nn.Linear(self.num_heads * self.Dh, dim)
+        self.q = nn.Linear(dim, self.Dh * num_heads)
+        self.v = nn.Linear(dim, self.Dh * num_heads)
+        self.k = nn.Linear(dim, self.Dh * num_heads)
+
+    def forward(self, x, attention_mask: Optional[torch.Tensor] = None):
+        H, S = self.num_heads, x.shape[1]
+        q, k, v = _split_heads(self.q(x), H), _split_heads(self.v(x), H), _split_heads(self.k(x), H)
+        cos, sin = self.xPos.cos_sin(S)
+        zeta = self.xPos.xpos_scale(S)
+        q = rotate_pairs(q, cos, sin, zeta)
+        k = rotate_pairs(k, cos, sin, zeta ** -1)
+        scores = (q @ k.transpose(-1, -2)) / math.sqrt(self.Dh * H)
+        future = torch.ones(S, S, dtype=torch.bool, device=x.device).triu(1)
+        scores = scores.masked_fill(future, float("-inf"))
+        if attention_mask is not None:
+            scores = scores + (1 - attention_mask[:, None, None, :]) * -1e9
+        w = torch.softmax(scores, dim=-1)
+        return self.multi_mad(_merge_heads(w @ v))
+
+
+# --------------------------------------------------------------------------------------
+# a8  temporal (lag-axis) attention                   reference: meant/temporal.py:15-60
+# --------------------------------------------------------------------------------------
+class temporal(nn.Module):
+    """Single query = last lag step (:39); keys/values = all L steps; no rotary, no
+    mask; same k/v naming swap and 1/sqrt(dim) scale (:38-39,44)."""
+
+    def __init__(self, num_heads: int, dim: int):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        self.Dh = dim // num_heads
+        self.atten_size = self.Dh * num_heads
+        self.multi_mad = nn.Linear(self.atten_size, dim)
+        self.q = nn.Linear(dim, self.atten_size)
+        self.v = nn.Linear(dim, self.atten_size)
+        self.k = nn.Linear(dim, self.atten_size)
+
+    def forward(self, x):
+        H = self.num_heads
+        q = _split_heads(self.q(x[:, -1:, :]), H)                 # b h 1 dh
+        k, v = _split_heads(self.v(x), H), _split_heads(self.k(x), H)
+        scores = (q @ k.transpose(-1, -2)) / math.sqrt(self.Dh * H)
+        w = torch.softmax(scores, dim=-1)
+        return self.multi_mad(_merge_heads(w @ v))                # b 1 dim
+
+
+# --------------------------------------------------------------------------------------
+# a9-a11  encoder blocks                               reference: meant/meant.py:35-145
+# --------------------------------------------------------------------------------------
+class visionEncoder(nn.Module):
+    """meant/meant.py:35-75: [RMSNorm, Linear, attention, RMSNorm, Linear] + residual,
+    then [RMSNorm, Linear, GELU(erf), RMSNorm, Linear] + residual."""
+
+    def __init__(self, dim: int, num_heads: int):
+        super().__init__()
+        self.posEmbed = RotaryTable(math.floor(dim / num_heads / 2), "pixel")      # :46-48
+        self.encode = nn.ModuleList([RMSNorm(dim), nn.Linear(dim, dim),
+                                     attention(num_heads, dim, self.posEmbed),
+                                     RMSNorm(dim), nn.Linear(dim, dim)])
+        self.encode2 = nn.ModuleList([RMSNorm(dim), nn.Linear(dim, dim), nn.GELU(),
+                                      RMSNorm(dim), nn.Linear(dim, dim)])
+
+    def forward(self, x):
+        h = x
+        for m in self.encode:
+            h = m(h)
+        x1 = h + x
+        h = x1
+        for m in self.encode2:
+            h = m(h)
+        return h + x1
+
+
+class languageEncoder(nn.Module):
+    """meant/meant.py:78-120.  Indices follow the reference's ModuleLists, which hold
+    Dropout(0.0) at encode[4] and Dropout(0.5) at encode2[4]; the oracle is an
+    eval-mode oracle, so both are identities here (kept as nn.Identity to preserve the
+    state_dict numbering)."""
+
+    def __init__(self, dim: int, num_heads: int):
+        super().__init__()
+        self.xPos = RotaryTable(48, "lang", use_xpos=True)                         # :88-92
+        self.encode = nn.ModuleList([RMSNorm(dim), nn.Linear(dim, dim),
+                                     xPosAttention(num_heads, dim, self.xPos),
+                                     RMSNorm(dim), nn.Identity(), nn.Linear(dim, dim)])
+        self.encode2 = nn.ModuleList([RMSNorm(dim), nn.Linear(dim, dim), nn.GELU(),
+                                      RMSNorm(dim), nn.Identity(), nn.Linear(dim, dim)])
+
+    def forward(self, x, attention_mask=None):
+        h = x
+        for m in self.encode:
+            h = m(h, attention_mask) if isinstance(m, xPosAttention) else m(h)
+        x1 = h + x
+        h = x1
+        for m in self.encode2:
+            h = m(h)
+        return h + x1
+
+
+class temporalEncoder(nn.Module):
+    """meant/meant.py:124-145 (norms=True) and the norm-less variants of
+    meant/meant_vision.py:79-105 / meant/meant_tweet.py:85-110 (norms=False)."""
+
+    def __init__(self, dim: int, num_heads: int, lag: int, norms: bool = True):
+        super().__init__()
+        self.temp_embedding = nn.Parameter(torch.randn(1, lag, dim))
+        if norms:
+            mods = [RMSNorm(dim), nn.Linear(dim, dim), temporal(num_heads, dim),
+                    RMSNorm(dim), nn.Linear(dim, dim)]
+        else:
+            mods = [nn.Linear(dim, dim), temporal(num_heads, dim), nn.Linear(dim, dim)]
+        self.temp_encode = nn.ModuleList(mods)
+
+    def forward(self, x):
+        x = x + self.temp_embedding                                # :141-142 (broadcast over b)
+        for m in self.temp_encode:
+            x = m(x)
+        return x
+
+
+def patchify(images, p: int):
+    """einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (meant/meant.py:194): channel is
+    the fastest-varying index inside a patch vector."""
+    b, c, H, W = images.shape
+    x = images.view(b, c, H // p, p, W // p, p)                   # b c h p1 w p2
+    x = x.permute(0, 2, 4, 3, 5, 1)                               # b h w p1 p2 c
+    return x.reshape(b, (H // p) * (W // p), p * p * c)
+
+
+class _PatchEmbed(nn.Sequential):
+    """Index 0 is the parameter-free rearrange, index 1 the Linear, so the key is
+    ``patchEmbed.1.weight`` as in the reference (meant/meant.py:193-195)."""
+
+    def __init__(self, patch_dim, dim, p):
+        super().__init__(nn.Identity(), nn.Linear(patch_dim, dim))
+        self.p = p
+
+    def forward(self, images):
+        return self[1](patchify(images, self.p))
+
+
+# --------------------------------------------------------------------------------------
+# a12  full model                                     reference: meant/meant.py:148-238
+# --------------------------------------------------------------------------------------
+class meant(nn.Module):
+    def __init__(self, text_dim, image_dim, price_dim, height, width, patch_res, lag,
+                 num_classes, embedding, flash=False, num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.lag = lag
+        self.dim = text_dim + image_dim
+        self.embedding = nn.ModuleList([embedding])
+        self.patchEmbed = _PatchEmbed(channels * patch_res * patch_res, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads) for _ in range(num_encoders)])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads) for _ in range(num_encoders)])
+        self.temporal_encoding = nn.ModuleList([temporalEncoder(self.dim, num_heads, lag)])
+        self.mlpHead = nn.ModuleList([RMSNorm(self.dim), nn.Linear(self.dim, num_classes), nn.Sigmoid()])
+
+    def forward(self, tweets, images, attention_mask=None):
+        B, L = images.shape[0], self.lag
+        words = tweets.reshape(B * L, tweets.shape[2])                              # :209
+        for m in self.embedding:
+            words = m(words)
+        if attention_mask is not None:
+            attention_mask = attention_mask.reshape(B * L, attention_mask.shape[2])  # :215
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask)
+        words = words.view(B, L, words.shape[1], words.shape[2])
+        img = images.reshape(B * L, *images.shape[2:])                               # :223
+        img = self.patchEmbed(img)
+        for enc in self.visionEncoders:
+            img = enc(img)
+        img = img.view(B, L, img.shape[1], img.shape[2])
+        fused = torch.cat((words.mean(dim=2), img.mean(dim=2)), dim=2)               # :231
+        for enc in self.temporal_encoding:
+            fused = enc(fused)
+        for m in self.mlpHead:
+            fused = m(fused)
+        return fused.squeeze(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a13  meant_vision                             reference: meant/meant_vision.py:107-165
+# --------------------------------------------------------------------------------------
+class meant_vision(nn.Module):
+    def __init__(self, image_dim, price_dim, height, width, patch_res, lag, num_classes,
+                 flash=False, num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.dim = image_dim
+        self.patchEmbed = _PatchEmbed(channels * patch_res * patch_res, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads) for _ in range(num_encoders)])
+        self.temporal_encoding = nn.ModuleList([temporalEncoder(self.dim, num_heads, lag, norms=False)])
+        self.mlpHead = nn.ModuleList([nn.LayerNorm(self.dim), nn.Linear(self.dim, num_classes), nn.Sigmoid()])
+
+    def forward(self, images):
+        B, L = images.shape[0], images.shape[1]
+        img = self.patchEmbed(images.reshape(B * L, *images.shape[2:]))
+        for enc in self.visionEncoders:
+            img = enc(img)
+        fused = img.view(B, L, img.shape[1], img.shape[2]).mean(dim=2)
+        for enc in self.temporal_encoding:
+            fused = enc(fused)
+        for m in self.mlpHead:
+            fused = m(fused)
+        return fused.squeeze(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a14  meant_tweet                               reference: meant/meant_tweet.py:114-167
+# --------------------------------------------------------------------------------------
+class meant_tweet(nn.Module):
+    """The reference's own languageEncoder copy ends in a NameError
+    (meant/meant_tweet.py:81); the evident intent (== meant/meant.py:109-120) is what is
+    restated, and what gen_golden.py patches in on the reference side."""
+
+    def __init__(self, text_dim, price_dim, lag, num_classes, embedding, flash=False,
+                 num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.dim, self.lag = text_dim, lag
+        self.embedding = nn.ModuleList([embedding])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads) for _ in range(num_encoders)])
+        self.temporal_encoding = nn.ModuleList([temporalEncoder(self.dim, num_heads, lag, norms=False)])
+        self.mlpHead = nn.ModuleList([nn.LayerNorm(self.dim), nn.Linear(self.dim, num_classes), nn.Sigmoid()])
+
+    def forward(self, tweets, attention_mask=None):
+        B, L = tweets.shape[0], self.lag
+        words = tweets.reshape(B * L, tweets.shape[2])
+        attention_mask = attention_mask.reshape(B * L, attention_mask.shape[2])       # :150 (required)
+        for m in self.embedding:
+            words = m(words)
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask)
+        fused = words.view(B, L, words.shape[1], words.shape[2]).mean(dim=2)
+        for enc in self.temporal_encoding:
+            fused = enc(fused)
+        for m in self.mlpHead:
+            fused = m(fused)
+        return fused.squeeze(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a15  meant_vqa                                   reference: meant/meant_vqa.py:143-234
+# --------------------------------------------------------------------------------------
+class meant_vqa(nn.Module):
+    """No lag axis and no cross-attention in the forward that actually runs
+    (:205-234): concat of the two mean-pools -> RMSNorm -> Linear -> Sigmoid.  The
+    ``multimodal_embedding`` / ``multimodal_encoding`` blocks are constructed (so their
+    weights are in the state_dict, :199-200) and never called."""
+
+    def __init__(self, text_dim, image_dim, price_dim, height, width, patch_res, lag,
+                 num_classes, embedding, flash=False, num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.dim = text_dim + image_dim
+        self.embedding = nn.ModuleList([embedding])
+        self.patchEmbed = _PatchEmbed(channels * patch_res * patch_res, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads) for _ in range(num_encoders)])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads) for _ in range(num_encoders)])
+        self.multimodal_embedding = nn.Sequential(nn.Linear(1, self.dim), nn.GELU(), RMSNorm(self.dim),
+                                                  nn.Linear(self.dim, self.dim))
+        self.multimodal_encoding = nn.ModuleList([visionEncoder(self.dim, num_heads)])
+        self.mlpHead = nn.ModuleList([RMSNorm(self.dim), nn.Linear(self.dim, num_classes), nn.Sigmoid()])
+
+    def forward(self, tweets, images, attention_mask=None):
+        words = tweets
+        for m in self.embedding:
+            words = m(words)
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask)
+        img = self.patchEmbed(images)
+        for enc in self.visionEncoders:
+            img = enc(img)
+        fused = torch.cat((words.mean(dim=1), img.mean(dim=1)), dim=1)
+        for m in self.mlpHead:
+            fused = m(fused)
+        return fused
+
+
+# --------------------------------------------------------------------------------------
+# deterministic weights / inputs shared by gen_golden.py, the tests and bench.py
+# (SURVEY.md section 8c "fixture recipe": numpy RandomState only, no torch RNG)
+# --------------------------------------------------------------------------------------
+def fill_weights_(model: nn.Module, seed: int = 1234) -> nn.Module:
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for key in sorted(sd):
+            t = sd[key]
+            if key.endswith("freqs") or key.endswith("xPos.scale") or key.endswith("pos_emb.scale"):
+                continue                                            # analytic tables
+            if not t.is_floating_point():
+                continue
+            z = torch.from_numpy(rs.standard_normal(tuple(t.shape)).astype("float32"))
+            if key.endswith(".scale") or (key.endswith(".weight") and t.dim() == 1):
+                v = 1.0 + 0.1 * z                                   # RMSNorm / LayerNorm gains
+            elif key.endswith("bias"):
+                v = 0.02 * z
+            elif key.endswith("temp_embedding"):
+                v = 0.5 * z
+            else:
+                v = z / math.sqrt(t.shape[-1])
+            t.copy_(v.to(t.dtype))
+    return model
+
+
+def cross_entropy_on_probs(out, target):
+    """in_loop_train.py:232 -- CrossEntropyLoss applied to the already-Sigmoid-ed output."""
+    return F.cross_entropy(out, target)

@@ -1,0 +1,174 @@
+"""Pin the CPU oracle (oracle/meant_oracle.py) to golden vectors produced by the
+reference itself (oracle/gen_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import meant_oracle as O
+
+TOL = 2e-5   # fp32 CPU <-> fp32 CPU, different op order
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_rmsnorm_kat_and_grads(golden):
+    g = golden("rmsnorm_768")
+    n = O.RMSNorm(4)
+    np.testing.assert_allclose(n(_t(g["kat_in"])).detach().numpy(), g["kat_out"], atol=1e-6)
+    np.testing.assert_allclose(g["kat_out"], [0.365148, 0.730297, 1.095445, 1.460593], atol=1e-6)
+    n = O.RMSNorm(768)
+    with torch.no_grad():
+        n.scale.copy_(_t(g["scale"]))
+    x = _t(g["x"]).requires_grad_()
+    y = n(x)
+    y.backward(_t(g["dy"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], atol=TOL)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], atol=TOL)
+    np.testing.assert_allclose(n.scale.grad.numpy(), g["dscale"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("S", [16, 64, 512])
+def test_xpos_rotation(golden, S):
+    g = golden("rotary_xpos48")
+    tab = O.RotaryTable(48, "lang", use_xpos=True)
+    np.testing.assert_allclose(tab.freqs.numpy(), g["freqs"], rtol=1e-6)
+    np.testing.assert_allclose(tab.scale.numpy(), g["scale"], rtol=1e-6)
+    cos, sin = tab.cos_sin(S)
+    z = tab.xpos_scale(S)
+    rq = O.rotate_pairs(_t(g[f"q{S}"]), cos, sin, z)
+    rk = O.rotate_pairs(_t(g[f"k{S}"]), cos, sin, z ** -1)
+    np.testing.assert_allclose(rq.numpy(), g[f"rq{S}"], atol=TOL)
+    np.testing.assert_allclose(rk.numpy(), g[f"rk{S}"], atol=TOL)
+    # lanes >= 48 untouched
+    np.testing.assert_array_equal(rq.numpy()[..., 48:], g[f"q{S}"][..., 48:])
+
+
+def test_xpos_survey_kat():
+    tab = O.RotaryTable(48, "lang", use_xpos=True)
+    assert abs(tab.scale[0].item() - 0.2857143) < 1e-6 and abs(tab.scale[23].item() - 0.9702381) < 1e-6
+    assert abs(tab.freqs[1].item() - 0.6812921) < 1e-6
+    cos, sin = tab.cos_sin(4)
+    z = tab.xpos_scale(4)
+    one = torch.ones(1, 1, 4, 64)
+    q = O.rotate_pairs(one, cos, sin, z)[0, 0, 3, :4]
+    k = O.rotate_pairs(one, cos, sin, z ** -1)[0, 0, 3, :4]
+    np.testing.assert_allclose(q.numpy(), [-1.128348, -0.846962, -1.343007, 0.433708], atol=2e-6)
+    np.testing.assert_allclose(k.numpy(), [-1.133883, -0.850787, -1.348598, 0.435372], atol=2e-6)
+
+
+@pytest.mark.parametrize("dim,N", [(32, 196), (48, 196), (32, 4)])
+def test_pixel_rotation(golden, dim, N):
+    g = golden("rotary_pixel")
+    tab = O.RotaryTable(dim, "pixel")
+    np.testing.assert_allclose(tab.freqs.numpy(), g[f"freqs_{dim}"], rtol=1e-6)
+    cos, sin = tab.cos_sin(N)
+    r = O.rotate_pairs(_t(g[f"t_{dim}_{N}"]), cos, sin)
+    np.testing.assert_allclose(r.numpy(), g[f"r_{dim}_{N}"], atol=TOL)
+
+
+def _check_module(g, mod, args):
+    O.fill_weights_(mod, 4321)
+    mod.eval()
+    x = _t(g["x"]).requires_grad_()
+    y = mod(x, *args)
+    y.backward(_t(g["dy"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], atol=TOL)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], atol=5e-5)
+    params = dict(mod.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        p = params[str(name)]
+        assert abs(p.grad.double().norm().item() - ref) <= 1e-4 * max(ref, 1e-3), name
+        ga = g["grad__" + str(name)]
+        got = p.grad if p.grad.numel() <= 4096 else p.grad[:4]
+        np.testing.assert_allclose(got.numpy(), ga, atol=1e-4, rtol=1e-4)
+
+
+def test_attention_module(golden):
+    g = golden("attention_h2_d128_n196")
+    _check_module(g, O.attention(2, 128, O.RotaryTable(32, "pixel")), ())
+
+
+@pytest.mark.parametrize("name", ["xposattention_h2_d128_s80", "xposattention_h2_d128_s512"])
+def test_xpos_attention_module(golden, name):
+    g = golden(name)
+    _check_module(g, O.xPosAttention(2, 128, O.RotaryTable(48, "lang", use_xpos=True)), (_t(g["mask"]),))
+
+
+def test_temporal_module(golden):
+    g = golden("temporal_h12_d1536_l12")
+    _check_module(g, O.temporal(12, 1536), ())
+
+
+def _check_model(g, model, inputs, grad_rtol=2e-4):
+    O.fill_weights_(model, 1234)
+    model.eval()
+    out = model(*inputs)
+    loss = O.cross_entropy_on_probs(out, _t(g["target"]))
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=TOL)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    params = dict(model.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        got = params[str(name)].grad.double().norm().item()
+        assert abs(got - ref) <= grad_rtol * max(ref, 1e-6) + 1e-7, (name, got, ref)
+    for key in g.files:
+        if key.startswith("grad__"):
+            p = params[key[6:]]
+            got = p.grad if p.grad.numel() <= 4096 else p.grad[:4]
+            np.testing.assert_allclose(got.numpy(), g[key], atol=1e-5, rtol=1e-3)
+
+
+def test_meant_tiny(golden):
+    g = golden("meant_tiny")
+    m = O.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=1, channels=4)
+    _check_model(g, m, (_t(g["in_tweets"]), _t(g["in_images"]), _t(g["in_mask"])))
+    # the numbers recorded in SURVEY.md 8(c) from the reference
+    np.testing.assert_allclose(g["out"], [[0.419537, 0.637061], [0.379703, 0.602564]], atol=1e-6)
+    assert abs(float(g["loss"]) - 0.6978624) < 1e-6
+
+
+def test_meant_tiny_two_layers(golden):
+    g = golden("meant_tiny_e2")
+    m = O.meant(128, 192, 4, 32, 48, 16, 2, 3, torch.nn.Embedding(50, 128), num_heads=2, num_encoders=2, channels=4)
+    _check_model(g, m, (_t(g["in_tweets"]), _t(g["in_images"]), _t(g["in_mask"])))
+
+
+def test_meant_tweet_c1(golden):
+    g = golden("meant_tweet_c1")
+    m = O.meant_tweet(128, 4, 1, 2, torch.nn.Embedding(1000, 128), num_heads=2, num_encoders=1)
+    _check_model(g, m, (_t(g["in_tweets"]), _t(g["in_mask"])))
+
+
+def test_meant_vision_tiny(golden):
+    g = golden("meant_vision_tiny")
+    m = O.meant_vision(128, 4, 32, 32, 16, 3, 2, num_heads=2, num_encoders=1, channels=4)
+    _check_model(g, m, (_t(g["in_images"]),))
+
+
+def test_meant_vqa_tiny(golden):
+    g = golden("meant_vqa_tiny")
+    m = O.meant_vqa(128, 128, 4, 32, 32, 16, 1, 7, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=1, channels=4)
+    _check_model(g, m, (_t(g["in_tweets"]), _t(g["in_images"]), _t(g["in_mask"])))
+
+
+def test_meant_vision_c2_full_width(golden):
+    g = golden("meant_vision_c2")
+    r = np.random.RandomState(102)
+    img = _t(r.standard_normal((2, 1, 4, 224, 224)).astype("float32"))
+    m = O.meant_vision(768, 4, 224, 224, 16, 1, 2, num_heads=12, num_encoders=1, channels=4)
+    _check_model(g, m, (img,), grad_rtol=1e-3)
+
+
+def test_meant_full_c3(golden):
+    """Full dims (lag 12, d 768, 12 heads, S 512, 224x224): outputs, loss, every grad norm."""
+    g = golden("meant_full_c3")
+    r = np.random.RandomState(99)
+    ids = _t(r.randint(0, 2000, (2, 12, 512)).astype("int64"))
+    img = _t(r.standard_normal((2, 12, 4, 224, 224)).astype("float32"))
+    mask = torch.ones(2, 12, 512)
+    mask[1, :, 400:] = 0
+    m = O.meant(768, 768, 4, 224, 224, 16, 12, 2, torch.nn.Embedding(2000, 768), num_heads=12, num_encoders=1)
+    _check_model(g, m, (ids, img, mask), grad_rtol=1e-3)
+    np.testing.assert_allclose(g["out"], [[0.713732, 0.527026], [0.701181, 0.410244]], atol=1e-6)
