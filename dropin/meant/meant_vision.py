@@ -1,0 +1,3 @@
+"""`meant.meant_vision` module path of the reference -> native classes."""
+from meant_amd.modules import *  # noqa: F401,F403
+from meant_amd.modules import meant_vision  # noqa: F401

@@ -1,0 +1,169 @@
+/*
+ * meant_hip.h  --  C ABI of libmeant_hip.so, the MI355X (gfx950 / CDNA4) implementation of the
+ * MEANT multimodal-encoder forward/backward hot path.
+ *
+ * The reference (biirving/meant) is pure Python; the native code on its hot path is what PyTorch
+ * dispatches to (ATen/cuBLAS kernels, flash-attn).  Each entry point below replaces the native
+ * work behind one reference call site (cited as file:line, relative to the reference root).  The host side
+ * (the Python modules under meant_amd/) binds these with ctypes and keeps the reference's nn.Module surface.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch);
+ *     the library never allocates, frees or retains device memory;
+ *   - dtype: MEANT_F32 (0) or MEANT_BF16 (1) is the storage type of activations ("act");
+ *     statistics, softmax, accumulators, parameter gradients and norm gains are always float;
+ *   - tensors are dense row-major in the documented shape; "ld" arguments are row strides in
+ *     elements where a tensor is a column slice of a wider buffer;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises;
+ *   - return value: 0 on success, a negative meant_status otherwise; meant_last_error() returns a
+ *     thread-local message.  Nothing aborts or throws across the boundary.
+ */
+#ifndef MEANT_HIP_H
+#define MEANT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum meant_dtype { MEANT_F32 = 0, MEANT_BF16 = 1 };
+
+enum meant_status {
+  MEANT_OK = 0,
+  MEANT_ERR_ARG = -1,         /* bad shape / null pointer / misalignment */
+  MEANT_ERR_UNSUPPORTED = -2, /* shape or dtype the kernels do not cover  */
+  MEANT_ERR_LAUNCH = -3,      /* hipGetLastError() after a launch         */
+  MEANT_ERR_WORKSPACE = -4    /* workspace too small                      */
+};
+
+/* epilogue flags of meant_linear_fwd */
+enum meant_epilogue {
+  MEANT_EPI_NONE = 0,
+  MEANT_EPI_GELU = 1,     /* y = gelu_erf(x W^T + b); optional pre-activation copy */
+  MEANT_EPI_RESIDUAL = 2, /* y = x W^T + b + residual                             */
+  MEANT_EPI_SIGMOID = 4   /* y = sigmoid(x W^T + b)                               */
+};
+
+int meant_version(void);
+const char* meant_last_error(void);
+/* number of compute units of the current device (for sizing partial-sum workspaces) */
+int meant_num_cus(void);
+
+/* ---- RMSNorm ---------------------------------------------------- utils/rms_norm.py:40-57
+ * y = scale * x * rinv,  rinv = 1 / (||x||_2 / sqrt(d) + eps)   (eps outside the sqrt)
+ * x,y: act [rows, d]; scale: float [d]; rinv: float [rows] (saved for backward).
+ * Optional fused inverted dropout on y (meant/meant.py:105,107): keep-prob 1-p, mask regenerated
+ * in backward from (seed, element index); p == 0 disables it. */
+int meant_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rinv, int64_t rows, int64_t d,
+                      float eps, float drop_p, uint64_t seed, int dtype, void* stream);
+/* dx: act [rows, d]; dscale: float [d] (overwritten); workspace: float [meant_rmsnorm_bwd_ws(d)] */
+size_t meant_rmsnorm_bwd_ws(int64_t rows, int64_t d);
+int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx,
+                      float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed,
+                      int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm (heads of meant_vision / meant_tweet) ----- meant/meant_vision.py:147
+ * stats: float [rows, 2] (mean, rstd). */
+int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                        int64_t rows, int64_t d, float eps, int dtype, void* stream);
+int meant_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                        float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ---- Linear ------------------- nn.Linear call sites meant/meant.py:59-64,101-107,132-136,195,204
+ *                                   and q/v/k/multi_mad in meant/attention.py:31-33,57-60 etc.
+ * y[M,N] = x[M,K] w[N,K]^T + bias[N]  (+ epilogue).  x,w,y,residual,preact: act dtype; bias float
+ * (may be NULL).  ldx/ldy/ldr: row strides.  preact (optional, EPI_GELU) receives x W^T + b. */
+int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
+                     int64_t ldr, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,
+                     int epilogue, int dtype, void* stream);
+/* dx[M,K] = dy[M,N] w[N,K]   (wT is w transposed, [K,N], act dtype: see meant_transpose2d) */
+int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, int64_t M,
+                        int64_t N, int64_t K, int dtype, void* stream);
+/* dw[N,K] += dy[M,N]^T x[M,K]  and  dbias[N] += colsum(dy)  -- float accumulators the caller zeroes
+ * (or pre-loads to accumulate across micro-batches).  dbias may be NULL. */
+int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias,
+                        int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+
+/* generic strided batched GEMM, float storage, f32 MFMA (exact fp32 products):
+ * C[b1,b2][m,n] = alpha * sum_k A[b1,b2](m,k) * B[b1,b2](k,n)   (+ C if accumulate)
+ * element (i,j) of X in batch (b1,b2) is at X + b1*sXb1 + b2*sXb2 + i*sXr + j*sXc. */
+int meant_gemm_f32_strided(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K,
+                           int64_t nb1, int64_t nb2, const int64_t* sA /*b1,b2,m,k*/,
+                           const int64_t* sB /*b1,b2,k,n*/, const int64_t* sC /*b1,b2,m,n*/, float alpha,
+                           int accumulate, void* stream);
+
+/* ---- rotary / xPos -------------------- meant/rotary_embedding_torch.py:31-44,96-110
+ * In-place on the q and k column blocks of a packed [T, 3*H*Dh] projection buffer:
+ *   out[c] = t[c]*A[pos,c] + rot(t)[c]*B[pos,c]  for lanes c < R of every head,
+ *   rot(t)[2j] = -t[2j+1], rot(t)[2j+1] = t[2j];   pos = row mod S.
+ * qa,qb,ka,kb: float [S, R] (cos*scale, sin*scale for q and for k).  `transpose` != 0 applies
+ * the adjoint (backward). */
+int meant_rotary_qk(void* qkv, int64_t T, int64_t S, int H, int Dh, int R, const float* qa, const float* qb,
+                    const float* ka, const float* kb, int transpose, int dtype, void* stream);
+
+/* ---- attention core -------- meant/attention.py:43-57, meant/xPosAttention.py:41-63
+ * qkv: act [G*S, 3*H*Dh] packed (q | k | v column blocks, already rotated); o: act [G*S, H*Dh];
+ * lse: float [G, H, S] (natural-log-sum-exp of the scaled, masked scores);
+ * key_mask: float [G, S] of {0,1} or NULL (adds (1-mask)*-1e9 to the scores);
+ * causal: scores[i,j] = -inf for j > i;  scale = 1/sqrt(H*Dh).
+ * bf16: fused flash kernels; f32: materialised scores in `workspace`. */
+size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
+int meant_attn_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H,
+                   int Dh, float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
+                   void* stream);
+/* dqkv: act [G*S, 3*H*Dh] (every element written); do_: act [G*S, H*Dh] */
+int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask,
+                   void* dqkv, int64_t G, int64_t S, int H, int Dh, float scale, int causal, int dtype,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- temporal attention core ----------------------------- meant/temporal.py:44-56
+ * q: act [B, H*Dh] (last lag step), kv: act [B*L, 2*H*Dh] packed (k | v); o: act [B, H*Dh];
+ * p: float [B, H, L] softmax weights (saved). */
+int meant_temporal_attn_fwd(const void* q, const void* kv, void* o, float* p, int64_t B, int L, int H, int Dh,
+                            float scale, int dtype, void* stream);
+int meant_temporal_attn_bwd(const void* q, const void* kv, const float* p, const void* do_, void* dq, void* dkv,
+                            int64_t B, int L, int H, int Dh, float scale, int dtype, void* stream);
+
+/* ---- patchify ------------------------------------------------------ meant/meant.py:194
+ * images: float or act [G, C, Hh, Ww] -> patches act [G*(Hh/p)*(Ww/p), p*p*C], channel fastest. */
+int meant_patchify(const void* images, int images_dtype, void* patches, int64_t G, int C, int Hh, int Ww, int p,
+                   int dtype, void* stream);
+
+/* ---- sequence mean-pool ------------------------------------------- meant/meant.py:231
+ * x: act [G, S, d] -> out[g, col_off : col_off+d] of an act [G, ld_out] buffer (the concat). */
+int meant_meanpool_fwd(const void* x, void* out, int64_t ld_out, int64_t col_off, int64_t G, int64_t S, int64_t d,
+                       int dtype, void* stream);
+int meant_meanpool_bwd(const void* dout, int64_t ld_out, int64_t col_off, void* dx, int64_t G, int64_t S, int64_t d,
+                       int dtype, void* stream);
+
+/* ---- small elementwise helpers ---- */
+/* y[r, :] = x[r, :] + v[(r mod period), :]  (temp_embedding add, meant/meant.py:141-142) */
+int meant_add_rowvec(const void* x, const float* v, void* y, int64_t rows, int64_t d, int64_t period, int dtype,
+                     void* stream);
+/* dv[period, d] (float, overwritten) = sum over rows r = i mod period of dy[r, :] */
+int meant_add_rowvec_bwd(const void* dy, float* dv, int64_t rows, int64_t d, int64_t period, int dtype, void* stream);
+/* dx = dy * gelu'(pre) */
+int meant_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
+/* dx = dy * y * (1-y) */
+int meant_sigmoid_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+/* y = a + b */
+int meant_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+/* dst(act dtype_dst) = src(dtype_src), n elements */
+int meant_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t n, void* stream);
+/* dst[c, r] (dtype_dst) = src[r, c] (dtype_src); src is [rows, cols] */
+int meant_transpose2d(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t rows, int64_t cols,
+                      void* stream);
+/* embedding gather: out act [n, d] = table float [V, d] rows ids[n] (int64); and its scatter-add backward
+ * into dtable float [V, d] (caller zeroes).            nn.Embedding at meant/meant.py:211 */
+int meant_embedding_fwd(const float* table, const int64_t* ids, void* out, int64_t n, int64_t d, int64_t V, int dtype,
+                        void* stream);
+int meant_embedding_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t n, int64_t d, int64_t V, int dtype,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEANT_HIP_H */

@@ -1,0 +1,81 @@
+"""ctypes binding of libmeant_hip.so (the C ABI declared in include/meant_hip.h).
+
+The product path has exactly one backend.  If the shared library is missing this module
+raises at import: there is no CPU or PyTorch-eager fallback (by design -- see DESIGN.md).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmeant_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SIGMOID = 0, 1, 2, 4
+
+_p, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/meant_hip.h one to one
+SIGNATURES = {
+    "meant_version": (_i, []),
+    "meant_last_error": (C.c_char_p, []),
+    "meant_num_cus": (_i, []),
+    "meant_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _f, _f, _u64, _i, _p]),
+    "meant_rmsnorm_bwd_ws": (_sz, [_i64, _i64]),
+    "meant_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _u64, _i, _p, _sz, _p]),
+    "meant_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p]),
+    "meant_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _sz, _p]),
+    "meant_linear_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p]),
+    "meant_linear_bwd_dx": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
+    "meant_linear_bwd_dw": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_gemm_f32_strided": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _f, _i, _p]),
+    "meant_rotary_qk": (_i, [_p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
+    "meant_attn_ws": (_sz, [_i64, _i64, _i, _i, _i]),
+    "meant_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _i, _p, _sz, _p]),
+    "meant_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _i, _p, _sz, _p]),
+    "meant_temporal_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
+    "meant_temporal_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
+    "meant_patchify": (_i, [_p, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "meant_meanpool_fwd": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p]),
+    "meant_meanpool_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_add_rowvec": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_add_rowvec_bwd": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_gelu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "meant_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "meant_add": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "meant_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
+    "meant_transpose2d": (_i, [_p, _i, _p, _i, _i64, _i64, _p]),
+    "meant_embedding_fwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_embedding_bwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+}
+
+
+class MeantLibraryMissing(ImportError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MeantLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C meant_amd/csrc`).  meant_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class MeantHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.meant_last_error().decode("utf-8", "replace")
+        raise MeantHipError(f"{what or 'libmeant_hip'} failed (status {rc}): {msg}")

@@ -1,0 +1,110 @@
+// extern "C" entry points for Linear and the attention core: argument checks + dtype dispatch.
+#include "internal.h"
+
+extern "C" int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual, int64_t ldr,
+                                void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K, int epilogue, int dtype,
+                                void* stream) {
+  MEANT_REQUIRE(x && w && y, MEANT_ERR_ARG, "linear_fwd: null pointer");
+  MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, MEANT_ERR_ARG, "linear_fwd: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  MEANT_REQUIRE(!(epilogue & MEANT_EPI_RESIDUAL) || residual, MEANT_ERR_ARG, "linear_fwd: residual epilogue without residual pointer");
+  if (!(epilogue & MEANT_EPI_RESIDUAL)) residual = nullptr;
+  if (dtype == MEANT_F32) {
+    MEANT_REQUIRE(!residual || ldr == ldy, MEANT_ERR_UNSUPPORTED, "linear_fwd(f32): residual stride must equal output stride");
+    GemmF32Args a{};
+    a.A = (const float*)x; a.B = (const float*)w; a.C = (float*)y;
+    a.M = M; a.N = N; a.K = K; a.nb1 = 1; a.nb2 = 1;
+    a.sA[2] = ldx; a.sA[3] = 1; a.sB[2] = 1; a.sB[3] = K; a.sC[2] = ldy; a.sC[3] = 1;
+    a.alpha = 1.f; a.bias = bias; a.residual = (const float*)residual; a.preact = (float*)preact; a.epilogue = epilogue;
+    return gemm_f32_launch(a, (hipStream_t)stream);
+  }
+  if (dtype == MEANT_BF16) {
+    GemmBf16Args a{};
+    a.A = (const bf16*)x; a.lda = ldx; a.B = (const bf16*)w; a.ldb = K; a.C = (bf16*)y; a.ldc = ldy;
+    a.M = M; a.N = N; a.K = K; a.bias = bias; a.residual = (const bf16*)residual; a.ldr = ldr; a.preact = (bf16*)preact;
+    a.epilogue = epilogue;
+    return gemm_bf16_nt_launch(a, (hipStream_t)stream);
+  }
+  meant_set_error("linear_fwd: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}
+
+extern "C" int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, int64_t M, int64_t N,
+                                   int64_t K, int dtype, void* stream) {
+  MEANT_REQUIRE(dy && wT && dx, MEANT_ERR_ARG, "linear_bwd_dx: null pointer");
+  MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && lddx >= K, MEANT_ERR_ARG, "linear_bwd_dx: bad shape");
+  if (dtype == MEANT_F32) {
+    GemmF32Args a{};
+    a.A = (const float*)dy; a.B = (const float*)wT; a.C = (float*)dx;
+    a.M = M; a.N = K; a.K = N; a.nb1 = 1; a.nb2 = 1;
+    a.sA[2] = lddy; a.sA[3] = 1; a.sB[2] = 1; a.sB[3] = N; a.sC[2] = lddx; a.sC[3] = 1;
+    a.alpha = 1.f;
+    return gemm_f32_launch(a, (hipStream_t)stream);
+  }
+  if (dtype == MEANT_BF16) {
+    GemmBf16Args a{};
+    a.A = (const bf16*)dy; a.lda = lddy; a.B = (const bf16*)wT; a.ldb = N; a.C = (bf16*)dx; a.ldc = lddx;
+    a.M = M; a.N = K; a.K = N;
+    return gemm_bf16_nt_launch(a, (hipStream_t)stream);
+  }
+  meant_set_error("linear_bwd_dx: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}
+
+extern "C" int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias, int64_t M,
+                                   int64_t N, int64_t K, int dtype, void* stream) {
+  MEANT_REQUIRE(dy && x && dw, MEANT_ERR_ARG, "linear_bwd_dw: null pointer");
+  MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K, MEANT_ERR_ARG, "linear_bwd_dw: bad shape");
+  if (dtype == MEANT_F32) {
+    GemmF32Args a{};
+    a.A = (const float*)dy; a.B = (const float*)x; a.C = dw;
+    a.M = N; a.N = K; a.K = M; a.nb1 = 1; a.nb2 = 1;
+    a.sA[2] = 1; a.sA[3] = lddy; a.sB[2] = ldx; a.sB[3] = 1; a.sC[2] = K; a.sC[3] = 1;
+    a.alpha = 1.f; a.accumulate = 1;
+    int rc = gemm_f32_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    if (dbias) return colsum_launch(dy, lddy, dbias, M, N, MEANT_F32, 1, (hipStream_t)stream);
+    return MEANT_OK;
+  }
+  if (dtype == MEANT_BF16)
+    return gemm_bf16_tn_launch((const bf16*)dy, lddy, (const bf16*)x, ldx, dw, dbias, M, N, K, (hipStream_t)stream);
+  meant_set_error("linear_bwd_dw: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}
+
+extern "C" size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype) {
+  return dtype == MEANT_F32 ? attn_f32_ws(G, S, H, Dh) : attn_bf16_ws(G, S, H, Dh);
+}
+
+static int attn_check(const char* name, int64_t G, int64_t S, int H, int Dh) {
+  MEANT_REQUIRE(G > 0 && S > 0 && H > 0 && Dh > 0, MEANT_ERR_ARG, "%s: bad shape G=%lld S=%lld H=%d Dh=%d", name, (long long)G, (long long)S, H, Dh);
+  return MEANT_OK;
+}
+
+extern "C" int meant_attn_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
+                              float scale, int causal, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(qkv && o && lse, MEANT_ERR_ARG, "attn_fwd: null pointer");
+  int rc = attn_check("attn_fwd", G, S, H, Dh);
+  if (rc) return rc;
+  if (dtype == MEANT_F32)
+    return attn_f32_fwd((const float*)qkv, (float*)o, lse, key_mask, G, S, H, Dh, scale, causal, workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == MEANT_BF16)
+    return attn_bf16_fwd((const bf16*)qkv, (bf16*)o, lse, key_mask, G, S, H, Dh, scale, causal, (hipStream_t)stream);
+  meant_set_error("attn_fwd: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}
+
+extern "C" int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask, void* dqkv,
+                              int64_t G, int64_t S, int H, int Dh, float scale, int causal, int dtype, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(qkv && o && do_ && lse && dqkv, MEANT_ERR_ARG, "attn_bwd: null pointer");
+  int rc = attn_check("attn_bwd", G, S, H, Dh);
+  if (rc) return rc;
+  if (dtype == MEANT_F32)
+    return attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)do_, lse, key_mask, (float*)dqkv, G, S, H, Dh, scale, causal,
+                        workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == MEANT_BF16)
+    return attn_bf16_bwd((const bf16*)qkv, (const bf16*)o, (const bf16*)do_, lse, key_mask, (bf16*)dqkv, G, S, H, Dh, scale, causal,
+                         workspace, workspace_bytes, (hipStream_t)stream);
+  meant_set_error("attn_bwd: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}

@@ -1,0 +1,110 @@
+// Shared device/host helpers for libmeant_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/meant_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void meant_set_error(const char* fmt, ...);
+
+#define MEANT_REQUIRE(cond, code, ...)      \
+  do {                                      \
+    if (!(cond)) {                          \
+      meant_set_error(__VA_ARGS__);         \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define MEANT_LAUNCH_CHECK(name)                                                     \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      meant_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return MEANT_ERR_LAUNCH;                                                       \
+    }                                                                                \
+  } while (0)
+
+static inline bool meant_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- storage-type helpers (math is always float) ------------------------------------------------
+template <typename T> struct Vec8;  // 8 contiguous elements
+template <> struct Vec8<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ float get(int i) const { return i < 4 ? lo[i] : hi[i - 4]; }
+  __device__ __forceinline__ void set(int i, float v) { if (i < 4) lo[i] = v; else hi[i - 4] = v; }
+};
+template <> struct Vec8<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T> __device__ __forceinline__ Vec8<T> load8(const T* p);
+template <> __device__ __forceinline__ Vec8<float> load8<float>(const float* p) {
+  Vec8<float> r; r.lo = *reinterpret_cast<const f32x4*>(p); r.hi = *reinterpret_cast<const f32x4*>(p + 4); return r;
+}
+template <> __device__ __forceinline__ Vec8<bf16> load8<bf16>(const bf16* p) {
+  Vec8<bf16> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const Vec8<T>& v);
+template <> __device__ __forceinline__ void store8<float>(float* p, const Vec8<float>& v) {
+  *reinterpret_cast<f32x4*>(p) = v.lo; *reinterpret_cast<f32x4*>(p + 4) = v.hi;
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const Vec8<bf16>& v) {
+  *reinterpret_cast<bf16x8*>(p) = v.v;
+}
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// 64-lane butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// counter-based uniform in [0,1): splitmix-style hash of (seed, index); same value in fwd and bwd
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+#define DISPATCH_DTYPE(dtype, T, ...)                                           \
+  do {                                                                          \
+    if ((dtype) == MEANT_F32) { using T = float; __VA_ARGS__; }                 \
+    else if ((dtype) == MEANT_BF16) { using T = bf16; __VA_ARGS__; }            \
+    else { meant_set_error("unknown dtype %d", (int)(dtype)); return MEANT_ERR_ARG; } \
+  } while (0)

@@ -1,0 +1,51 @@
+// Internal (non-exported) interfaces between the translation units of libmeant_hip.so.
+#pragma once
+#include "common.h"
+
+// Generic strided batched fp32 GEMM on the f32 MFMA (exact fp32 products, v_mfma_f32_32x32x2_f32):
+//   C(b1,b2)[m,n] = act(alpha * sum_k A(m,k) B(k,n) + bias[n]) (+ residual(m,n)) (+ C if accumulate)
+struct GemmF32Args {
+  const float* A; const float* B; float* C;
+  int64_t M, N, K, nb1, nb2;
+  int64_t sA[4];  // b1, b2, m, k
+  int64_t sB[4];  // b1, b2, k, n
+  int64_t sC[4];  // b1, b2, m, n
+  float alpha;
+  int accumulate;
+  const float* bias;        // [N] or null
+  const float* residual;    // same strides as C, or null
+  float* preact;            // same strides as C, or null (value before the activation)
+  int epilogue;             // meant_epilogue flags
+};
+int gemm_f32_launch(const GemmF32Args& a, hipStream_t stream);
+
+// bf16 MFMA GEMMs (gemm_bf16.hip).  All operands K-contiguous ("NT"): C[M,N] = A[M,K] B[N,K]^T.
+struct GemmBf16Args {
+  const bf16* A; int64_t lda;
+  const bf16* B; int64_t ldb;
+  bf16* C; int64_t ldc;
+  int64_t M, N, K;
+  const float* bias;        // [N] or null
+  const bf16* residual; int64_t ldr;
+  bf16* preact;             // ldc stride, or null
+  int epilogue;
+};
+int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream);
+// dW[N,K] (float, +=) = dY[M,N]^T X[M,K], reduction over the token axis M; dbias[N] += colsum(dY)
+int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias,
+                        int64_t M, int64_t N, int64_t K, hipStream_t stream);
+
+// column sums: out[N] (+)= sum_m x[m, n]
+int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, int accumulate, hipStream_t stream);
+
+// attention cores
+int attn_f32_fwd(const float* qkv, float* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
+                 float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+int attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, const float* key_mask, float* dqkv,
+                 int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t attn_f32_ws(int64_t G, int64_t S, int H, int Dh);
+int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
+                  float scale, int causal, hipStream_t stream);
+int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv,
+                  int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh);

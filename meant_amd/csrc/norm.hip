@@ -1,0 +1,335 @@
+// K1: RMSNorm / LayerNorm forward + backward.  HBM-bound streaming kernels.
+//   one 64-lane wavefront per row, 16-byte (8-element bf16 / 2x16-byte f32) loads, the row kept in
+//   registers between the reduction and the normalisation (one read + one write per element),
+//   butterfly reduction over the wave, gain-gradient partials reduced per block then by a second
+//   tiny kernel (no atomics -> bitwise reproducible).
+// Reference semantics: utils/rms_norm.py:40-57 (eps added to the RMS, outside the sqrt).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 4;               // chunks of 8 per lane kept in registers -> d <= 2048
+constexpr int NORM_THREADS = 256;     // 4 waves = 4 rows in flight per block
+constexpr int NORM_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ float keep_scale(float p, uint64_t seed, uint64_t idx) {
+  return hash_uniform(seed, idx) >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                    T* __restrict__ y, float* __restrict__ rinv_out,
+                                                                    int64_t rows, int d, float eps, float drop_p,
+                                                                    uint64_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  const float inv_sqrt_d = rsqrtf((float)d);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const T* xr = x + row * d;
+    Vec8<T> v[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        v[c] = load8<T>(xr + ch * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float f = v[c].get(i); ss += f * f; }
+      }
+    }
+    ss = wave_sum(ss);
+    const float r = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+    if (lane == 0) rinv_out[row] = r;
+    T* yr = y + row * d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + ch * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(scale + ch * 8 + 4);
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float val = (i < 4 ? g0[i] : g1[i - 4]) * (v[c].get(i) * r);
+          if (drop_p > 0.f) val *= keep_scale(drop_p, seed, (uint64_t)row * d + ch * 8 + i);
+          o.set(i, val);
+        }
+        store8<T>(yr + ch * 8, o);
+      }
+    }
+  }
+}
+
+// dx_j = r * g_j dy_j  -  x_j * c * r^2 / (n sqrt(d)),  c = sum_i g_i dy_i x_i,  n sqrt(d) = (1/r - eps) d
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ rinv, T* __restrict__ dx,
+                                                                    float* __restrict__ partial, int64_t rows, int d,
+                                                                    float eps, float drop_p, uint64_t seed) {
+  __shared__ float red[4][512];   // reused per chunk: [wave][64 lanes * 8]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float gacc[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
+
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const T* xr = x + row * d;
+    const T* dyr = dy + row * d;
+    const float r = rinv[row];
+    Vec8<T> xv[MAXC];
+    float gd[MAXC][8];
+    float cdot = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        xv[c] = load8<T>(xr + ch * 8);
+        const Vec8<T> dv = load8<T>(dyr + ch * 8);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + ch * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(scale + ch * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float dyi = dv.get(i);
+          if (drop_p > 0.f) dyi *= keep_scale(drop_p, seed, (uint64_t)row * d + ch * 8 + i);
+          const float xi = xv[c].get(i);
+          gacc[c][i] += dyi * xi * r;
+          const float t = (i < 4 ? g0[i] : g1[i - 4]) * dyi;
+          gd[c][i] = t;
+          cdot += t * xi;
+        }
+      }
+    }
+    cdot = wave_sum(cdot);
+    const float nsd = (1.0f / r - eps) * (float)d;          // ||x|| * sqrt(d)
+    const float k = nsd > 0.f ? cdot * r * r / nsd : 0.f;
+    T* dxr = dx + row * d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.set(i, r * gd[c][i] - k * xv[c].get(i));
+        store8<T>(dxr + ch * 8, o);
+      }
+    }
+  }
+  // block reduction of the gain-gradient partials: 4 waves -> 1 row of `partial`
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = gacc[c][i];
+    __syncthreads();
+    if (wave == 0) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float s = red[0][lane * 8 + i] + red[1][lane * 8 + i] + red[2][lane * 8 + i] + red[3][lane * 8 + i];
+          partial[(int64_t)blockIdx.x * d + ch * 8 + i] = s;
+        }
+      }
+    }
+  }
+}
+
+// out[j] = sum_p partial[p, j]   (and optionally a second array at partial + np*d)
+__global__ void colreduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int np, int d) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  float s = 0.f;
+  for (int p = 0; p < np; ++p) s += partial[(int64_t)p * d + j];
+  out[j] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, T* __restrict__ y,
+                                                                      float* __restrict__ stats, int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const T* xr = x + row * d;
+    Vec8<T> v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        v[c] = load8<T>(xr + ch * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[c].get(i);
+      }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float t = v[c].get(i) - mean; q += t * t; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    T* yr = y + row * d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.set(i, (v[c].get(i) - mean) * rstd * gamma[ch * 8 + i] + beta[ch * 8 + i]);
+        store8<T>(yr + ch * 8, o);
+      }
+    }
+  }
+}
+
+// one wave per row; dgamma/dbeta partials per block written to partial[2][gridDim][d]
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ stats, T* __restrict__ dx,
+                                                                      float* __restrict__ partial, int64_t rows, int d) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float ga[MAXC][8], ba[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ga[c][i] = 0.f; ba[c][i] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[MAXC][8], gd[MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const Vec8<T> xv = load8<T>(x + row * d + ch * 8);
+        const Vec8<T> dv = load8<T>(dy + row * d + ch * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float h = (xv.get(i) - mean) * rstd;
+          const float dyi = dv.get(i);
+          xh[c][i] = h;
+          ga[c][i] += dyi * h;
+          ba[c][i] += dyi;
+          const float t = dyi * gamma[ch * 8 + i];
+          gd[c][i] = t;
+          s1 += t;
+          s2 += t * h;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.set(i, rstd * (gd[c][i] - s1 - xh[c][i] * s2));
+        store8<T>(dx + row * d + ch * 8, o);
+      }
+    }
+  }
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = which ? ba[c][i] : ga[c][i];
+      __syncthreads();
+      if (wave == 0) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            partial[((int64_t)which * gridDim.x + blockIdx.x) * d + ch * 8 + i] =
+                red[0][lane * 8 + i] + red[1][lane * 8 + i] + red[2][lane * 8 + i] + red[3][lane * 8 + i];
+        }
+      }
+    }
+  }
+}
+
+inline int norm_blocks(int64_t rows) {
+  int64_t b = ceil_div(rows, 4);
+  return (int)(b < 1 ? 1 : (b > NORM_MAX_BLOCKS ? NORM_MAX_BLOCKS : b));
+}
+
+}  // namespace
+
+extern "C" int meant_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rinv, int64_t rows, int64_t d,
+                                 float eps, float drop_p, uint64_t seed, int dtype, void* stream) {
+  MEANT_REQUIRE(x && scale && y && rinv, MEANT_ERR_ARG, "rmsnorm_fwd: null pointer");
+  MEANT_REQUIRE(rows >= 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512, MEANT_ERR_UNSUPPORTED,
+                "rmsnorm_fwd: d=%lld must be a multiple of 8 and <= %d", (long long)d, MAXC * 512);
+  MEANT_REQUIRE(meant_aligned16(x) && meant_aligned16(y) && meant_aligned16(scale), MEANT_ERR_ARG, "rmsnorm_fwd: 16-byte alignment");
+  MEANT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MEANT_ERR_ARG, "rmsnorm_fwd: drop_p out of range");
+  if (rows == 0) return MEANT_OK;
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(rmsnorm_fwd_kernel<T>, dim3(norm_blocks(rows)), dim3(NORM_THREADS), 0, (hipStream_t)stream,
+                                    (const T*)x, scale, (T*)y, rinv, rows, (int)d, eps, drop_p, seed));
+  MEANT_LAUNCH_CHECK("rmsnorm_fwd");
+  return MEANT_OK;
+}
+
+extern "C" size_t meant_rmsnorm_bwd_ws(int64_t rows, int64_t d) { return (size_t)norm_blocks(rows) * d * sizeof(float) * 2; }
+
+extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx,
+                                 float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed, int dtype,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd: null pointer");
+  MEANT_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd: unsupported d=%lld", (long long)d);
+  MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd: workspace too small");
+  const int nb = norm_blocks(rows);
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
+                                    (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, eps, drop_p, seed));
+  MEANT_LAUNCH_CHECK("rmsnorm_bwd");
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, dscale, nb, (int)d);
+  MEANT_LAUNCH_CHECK("rmsnorm_bwd/colreduce");
+  return MEANT_OK;
+}
+
+extern "C" int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                   int64_t rows, int64_t d, float eps, int dtype, void* stream) {
+  MEANT_REQUIRE(x && gamma && beta && y && stats, MEANT_ERR_ARG, "layernorm_fwd: null pointer");
+  MEANT_REQUIRE(rows > 0 && d % 8 == 0 && d <= MAXC * 512, MEANT_ERR_UNSUPPORTED, "layernorm_fwd: unsupported d=%lld", (long long)d);
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(norm_blocks(rows)), dim3(NORM_THREADS), 0, (hipStream_t)stream,
+                                    (const T*)x, gamma, beta, (T*)y, stats, rows, (int)d, eps));
+  MEANT_LAUNCH_CHECK("layernorm_fwd");
+  return MEANT_OK;
+}
+
+extern "C" int meant_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                                   float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta && workspace, MEANT_ERR_ARG, "layernorm_bwd: null pointer");
+  MEANT_REQUIRE(rows > 0 && d % 8 == 0 && d <= MAXC * 512, MEANT_ERR_UNSUPPORTED, "layernorm_bwd: unsupported d=%lld", (long long)d);
+  MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
+  const int nb = norm_blocks(rows);
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
+                                    (const T*)x, gamma, stats, (T*)dx, (float*)workspace, rows, (int)d));
+  MEANT_LAUNCH_CHECK("layernorm_bwd");
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, dgamma, nb, (int)d);
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace + (size_t)nb * d, dbeta, nb, (int)d);
+  MEANT_LAUNCH_CHECK("layernorm_bwd/colreduce");
+  return MEANT_OK;
+}

@@ -1,0 +1,465 @@
+"""Host-side mirror of the reference's nn.Module surface for the encoder hot path.
+
+Same class names, constructor / forward signatures and state_dict keys as the reference
+(top-level tree), so `meant.meant(...)`, checkpoints and the training
+drivers drop in.  The arithmetic is NOT here: every forward below is a short sequence of
+calls into libmeant_hip.so through meant_amd.ops (fused QKV+rotary+attention, Linear with
+bias/GELU/residual/sigmoid epilogues, RMSNorm with fused dropout, mean-pool+concat, temporal
+attention).  There is no eager fallback: tensors must live on an MI355X.
+
+Reference map (file:line under the reference root):
+  RMSNorm              utils/rms_norm.py:16-57
+  RotaryEmbedding      meant/rotary_embedding_torch.py:58-147  (only what the path uses)
+  attention            meant/attention.py:11-62
+  xPosAttention        meant/xPosAttention.py:11-66
+  temporal             meant/temporal.py:12-60
+  visionEncoder / languageEncoder / temporalEncoder / meant    meant/meant.py:35-238
+  meant_vision         meant/meant_vision.py:79-165
+  meant_tweet          meant/meant_tweet.py:85-167
+  meant_vqa            meant/meant_vqa.py:143-234
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import EPI_NONE, EPI_GELU, EPI_SIGMOID
+
+
+# ------------------------------------------------------------------------------------------
+# precision tier selection
+def resolve_compute_dtype(module: nn.Module, like: Optional[torch.Tensor]) -> torch.dtype:
+    """bf16 when the caller runs under torch.autocast (the reference trains under fp16 autocast,
+    in_loop_train.py:215) or hands over half-precision pixels; otherwise fp32.  A model-level
+    override is `model.compute_dtype = torch.bfloat16`."""
+    forced = getattr(module, "compute_dtype", None)
+    if forced is not None:
+        return forced
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    if like is not None and like.dtype in (torch.bfloat16, torch.float16):
+        return torch.bfloat16
+    return torch.float32
+
+
+# ------------------------------------------------------------------------------------------
+class RMSNorm(nn.Module):
+    """utils/rms_norm.py:16-57.  Only the full-width, bias-free form (p=-1, bias=False) that the
+    path uses is implemented natively; the partial/bias variants raise."""
+
+    def __init__(self, d, p=-1., eps=1e-8, bias=False):
+        super().__init__()
+        if bias or (0. <= p <= 1.):
+            raise NotImplementedError("meant_amd.RMSNorm: partial (p) / bias variants are not on the MEANT hot path")
+        self.eps, self.d, self.p, self.bias = eps, d, p, bias
+        self.scale = nn.Parameter(torch.ones(d))
+
+    def forward(self, x, drop_p: float = 0.0, seed: int = 0):
+        return ops.rmsnorm(x, self.scale, self.eps, drop_p, seed)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return ops.layernorm(x, self.weight, self.bias, self.eps)
+
+
+class Linear(nn.Linear):
+    def forward(self, x, residual=None, epilogue=EPI_NONE):
+        return ops.linear(x, self.weight, self.bias, residual, epilogue)
+
+
+class RotaryEmbedding(nn.Module):
+    """The subset of meant/rotary_embedding_torch.py:58-147 the path needs: `freqs` (frozen
+    Parameter) and the xPos `scale` buffer under the reference's names, plus the per-length
+    tables the HIP rotary kernel consumes.  Tables are built the reference's way (fp32 angles
+    pos*freq, :141; xPos power (pos - S//2)/scale_base, :121; block-concatenated scale, :125)."""
+
+    def __init__(self, dim, custom_freqs=None, freqs_for='lang', theta=10000, max_freq=10, num_freqs=1,
+                 learned_freq=False, use_xpos=False, xpos_scale_base=512):
+        super().__init__()
+        if custom_freqs is not None:
+            freqs = custom_freqs
+        elif freqs_for == 'lang':
+            freqs = 1. / (theta ** (torch.arange(0, dim, 2)[:(dim // 2)].float() / dim))
+        elif freqs_for == 'pixel':
+            freqs = torch.linspace(1., max_freq / 2, dim // 2) * math.pi
+        elif freqs_for == 'constant':
+            freqs = torch.ones(num_freqs).float()
+        else:
+            raise ValueError(f'unknown modality {freqs_for}')
+        if learned_freq:
+            raise NotImplementedError("meant_amd.RotaryEmbedding: learned_freq is not on the MEANT hot path")
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+        self.use_xpos = use_xpos
+        self.scale_base = xpos_scale_base
+        if use_xpos:
+            self.register_buffer('scale', (torch.arange(0, dim, 2) + 0.4 * dim) / (1.4 * dim))
+        else:
+            self.register_buffer('scale', None)
+        self._tables = {}
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st['_tables'] = {}
+        return st
+
+    @property
+    def rot_dim(self) -> int:
+        return 2 * self.freqs.numel()
+
+    def tables(self, seq_len: int, device) -> tuple:
+        """(qa, qb, ka, kb) float32 [S, R] on `device`: out = t*a + rot(t)*b."""
+        key = (seq_len, str(device), self.freqs._version, self.freqs.data_ptr())
+        hit = self._tables.get(key)
+        if hit is not None:
+            return hit
+        with torch.no_grad():
+            f = self.freqs.detach().float().cpu()
+            pos = torch.arange(seq_len)
+            ang = torch.repeat_interleave(pos.to(f.dtype)[:, None] * f[None, :], 2, dim=-1)
+            cos, sin = ang.cos(), ang.sin()
+            if self.use_xpos:
+                power = (pos - seq_len // 2) / self.scale_base
+                s = self.scale.detach().float().cpu()[None, :] ** power[:, None]
+                s = torch.cat((s, s), dim=-1)
+                si = s ** -1
+                t = (cos * s, sin * s, cos * si, sin * si)
+            else:
+                t = (cos, sin, cos, sin)
+            t = tuple(x.contiguous().to(device) for x in t)
+            if not self.use_xpos:
+                t = (t[0], t[1], t[0], t[1])
+        self._tables = {k: v for k, v in self._tables.items() if k[2:] == key[2:]}
+        self._tables[key] = t
+        return t
+
+
+# ------------------------------------------------------------------------------------------
+class attention(nn.Module):
+    """meant/attention.py:11-62: MHA over patches, pixel rotary on q,k, no mask, scale 1/sqrt(dim).
+    The Linear named `v` produces KEYS and the one named `k` produces VALUES (:36-37)."""
+
+    def __init__(self, num_heads, dim, pos_emb: RotaryEmbedding, mask=False, droput=0.):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        self.Dh = int(dim / num_heads)
+        self.dropout = nn.Dropout(droput)
+        self.pos_emb = pos_emb
+        self.mask = mask
+        self.softmax = nn.Softmax(dim=-1)
+        self.multi_mad = Linear(self.num_heads * self.Dh, self.dim)
+        self.q = Linear(self.dim, self.Dh * self.num_heads)
+        self.v = Linear(self.dim, self.Dh * self.num_heads)
+        self.k = Linear(self.dim, self.Dh * self.num_heads)
+
+    def core(self, x):
+        tables = self.pos_emb.tables(x.shape[1], x.device) if self.pos_emb is not None else None
+        return ops.qkv_attention(x, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,
+                                 tables, None, bool(self.mask), self.num_heads)
+
+    def forward(self, input):
+        out = self.multi_mad(self.core(input))
+        if self.training and self.dropout.p > 0:
+            out = self.dropout(out)
+        return out
+
+
+class xPosAttention(nn.Module):
+    """meant/xPosAttention.py:11-66: as `attention` with xPos on q,k (:39), always-causal mask
+    (:43-50) and the additive (1-mask)*-1e9 key-padding term (:54-56)."""
+
+    def __init__(self, num_heads, dim, xPos: RotaryEmbedding, mask=True, droput=0.):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        self.Dh = int(dim / num_heads)
+        self.dropout = nn.Dropout(droput)
+        self.xPos = xPos
+        self.mask = mask
+        self.softmax = nn.Softmax(dim=-1)
+        self.multi_mad = Linear(self.num_heads * self.Dh, self.dim)
+        self.q = Linear(self.dim, self.Dh * self.num_heads)
+        self.v = Linear(self.dim, self.Dh * self.num_heads)
+        self.k = Linear(self.dim, self.Dh * self.num_heads)
+
+    def core(self, x, attention_mask=None):
+        tables = self.xPos.tables(x.shape[1], x.device)
+        return ops.qkv_attention(x, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,
+                                 tables, attention_mask, bool(self.mask), self.num_heads)
+
+    def forward(self, input, attention_mask=None):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("meant_amd.xPosAttention: dropout on the score matrix (droput>0) is not supported")
+        return self.multi_mad(self.core(input, attention_mask))
+
+
+class temporal(nn.Module):
+    """meant/temporal.py:12-60: the query is the last lag step only (:39), keys/values all L steps."""
+
+    def __init__(self, num_heads, dim, mask=False, droput=0.):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        self.Dh = int(dim / num_heads)
+        self.dropout = nn.Dropout(droput)
+        self.mask = mask
+        self.softmax = nn.Softmax(dim=-1)
+        self.multi_mad = Linear(self.num_heads * self.Dh, self.dim)
+        self.atten_size = self.Dh * self.num_heads
+        self.q = Linear(self.dim, self.atten_size)
+        self.v = Linear(self.dim, self.atten_size)
+        self.k = Linear(self.dim, self.atten_size)
+
+    def forward(self, input):
+        o = ops.temporal_attention(input, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,
+                                   self.num_heads)
+        return self.multi_mad(o)
+
+
+# ------------------------------------------------------------------------------------------
+def _seed() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class visionEncoder(nn.Module):
+    """meant/meant.py:35-75."""
+
+    def __init__(self, dim, num_heads, flash=False):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.posEmbed = RotaryEmbedding(dim=math.floor(dim / num_heads / 2), freqs_for='pixel')
+        atten = attention(num_heads, dim, self.posEmbed)          # `flash` ignored: single HIP backend
+        self.encode = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), atten, RMSNorm(dim), Linear(dim, dim)])
+        self.encode2 = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), nn.GELU(), RMSNorm(dim), Linear(dim, dim)])
+
+    def forward(self, input):
+        e, e2 = self.encode, self.encode2
+        h = e[1](e[0](input))
+        h = e[3](e[2](h))
+        x1 = e[4](h, residual=input)
+        h = e2[1](e2[0](x1), epilogue=EPI_GELU)
+        return e2[4](e2[3](h), residual=x1)
+
+
+class languageEncoder(nn.Module):
+    """meant/meant.py:78-120.  Dropout(dropout) at encode[4] and the default-p Dropout() at
+    encode2[4] (:105,:107) are fused into the preceding RMSNorm kernel in training mode."""
+
+    def __init__(self, dim, num_heads, dropout=0.0, flash=False):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.xPos = RotaryEmbedding(dim=48, use_xpos=True)
+        att = xPosAttention(num_heads, dim, self.xPos)
+        self.encode = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), att, RMSNorm(dim), nn.Dropout(dropout), Linear(dim, dim)])
+        self.encode2 = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), nn.GELU(), RMSNorm(dim), nn.Dropout(), Linear(dim, dim)])
+
+    def forward(self, input, attention_mask=None):
+        e, e2 = self.encode, self.encode2
+        p1 = e[4].p if self.training else 0.0
+        p2 = e2[4].p if self.training else 0.0
+        h = e[1](e[0](input))
+        h = e[2](h, attention_mask)
+        h = e[3](h, drop_p=p1, seed=_seed() if p1 > 0 else 0)
+        x1 = e[5](h, residual=input)
+        h = e2[1](e2[0](x1), epilogue=EPI_GELU)
+        h = e2[3](h, drop_p=p2, seed=_seed() if p2 > 0 else 0)
+        return e2[5](h, residual=x1)
+
+
+class temporalEncoder(nn.Module):
+    """meant/meant.py:124-145; `norms=False` gives the variant of meant/meant_vision.py:79-105 and
+    meant/meant_tweet.py:85-110 (no RMSNorms, so temp_encode has 3 entries)."""
+
+    def __init__(self, dim, num_heads, lag, norms=True):
+        super().__init__()
+        self.dim, self.num_heads, self.lag = dim, num_heads, lag
+        self.temp_embedding = nn.Parameter(torch.randn(1, lag, dim))
+        if norms:
+            mods = [RMSNorm(dim), Linear(dim, dim), temporal(num_heads, dim), RMSNorm(dim), Linear(dim, dim)]
+        else:
+            mods = [Linear(dim, dim), temporal(num_heads, dim), Linear(dim, dim)]
+        self.temp_encode = nn.ModuleList(mods)
+
+    def forward(self, x):
+        x = ops.add_rowvec(x, self.temp_embedding)
+        for mod in self.temp_encode:
+            x = mod(x)
+        return x
+
+
+class _Patchify(nn.Module):
+    """einops Rearrange('b c (h p1) (w p2) -> b (h w) (p1 p2 c)') of meant/meant.py:194, emitting the
+    compute dtype.  Parameter-free, sits at index 0 so the Linear keeps the key `patchEmbed.1.*`."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+        self.out_dtype = torch.float32
+
+    def forward(self, images):
+        return ops.patchify(images, self.p, self.out_dtype)
+
+
+class _PatchEmbed(nn.Sequential):
+    def __init__(self, patch_dim, dim, p):
+        super().__init__(_Patchify(p), Linear(patch_dim, dim))
+
+    def forward(self, images, dtype=torch.float32):
+        self[0].out_dtype = dtype
+        return self[1](self[0](images))
+
+
+def _embed(mods, ids, dtype):
+    """meant/meant.py:210-211.  A plain nn.Embedding is served by the HIP gather kernel; any other
+    user module (e.g. HF RobertaEmbeddings) is called as is and its output cast."""
+    x = ids
+    for mod in mods:
+        if isinstance(mod, nn.Embedding) and mod.max_norm is None and not mod.sparse and x.dtype in (torch.int64, torch.int32):
+            x = ops.embedding(x, mod.weight, dtype)
+        else:
+            x = mod(x)
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    return x
+
+
+def _head(mods, x):
+    """[norm, Linear, Sigmoid] heads (meant/meant.py:204): the sigmoid rides the GEMM epilogue."""
+    x = mods[0](x)
+    if isinstance(mods[2], nn.Sigmoid):
+        return mods[1](x, epilogue=EPI_SIGMOID)
+    return mods[2](mods[1](x))
+
+
+class meant(nn.Module):
+    """meant/meant.py:148-238."""
+
+    def __init__(self, text_dim, image_dim, price_dim, height, width, patch_res, lag, num_classes, embedding, flash=False,
+                 num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.lag, self.text_dim, self.image_dim = lag, text_dim, image_dim
+        self.dim = text_dim + image_dim
+        self.num_heads = num_heads
+        self.channels = channels
+        self.patch_dim = channels * patch_res * patch_res
+        self.n = int((height * width) / (patch_res ** 2))
+        self.embedding = nn.ModuleList([embedding])
+        self.patchEmbed = _PatchEmbed(self.patch_dim, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.temporal_encoding = nn.ModuleList([temporalEncoder(self.dim, num_heads, lag)])
+        self.mlpHead = nn.ModuleList([RMSNorm(self.dim), Linear(self.dim, num_classes), nn.Sigmoid()])
+        self.compute_dtype = None
+
+    def forward(self, tweets, images, attention_mask=None):
+        dt = resolve_compute_dtype(self, images)
+        B = images.shape[0]
+        words = _embed(self.embedding, tweets.reshape(B * self.lag, tweets.shape[2]), dt)
+        if attention_mask is not None:
+            attention_mask = attention_mask.reshape(B * self.lag, attention_mask.shape[2])
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask)
+        img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
+        for enc in self.visionEncoders:
+            img = enc(img)
+        fused = ops.meanpool_cat(words, img).view(B, self.lag, self.dim)
+        for enc in self.temporal_encoding:
+            fused = enc(fused)
+        return _head(self.mlpHead, fused).squeeze(dim=1).float()
+
+
+class meant_vision(nn.Module):
+    """meant/meant_vision.py:107-165."""
+
+    def __init__(self, image_dim, price_dim, height, width, patch_res, lag, num_classes, flash=False, num_heads=8,
+                 num_encoders=1, channels=4):
+        super().__init__()
+        self.dim = image_dim
+        self.num_heads = num_heads
+        self.channels = channels
+        self.patch_dim = channels * patch_res * patch_res
+        self.n = int((height * width) / (patch_res ** 2))
+        self.patchEmbed = _PatchEmbed(self.patch_dim, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.temporal_encoding = nn.ModuleList([temporalEncoder(self.dim, num_heads, lag, norms=False)])
+        self.mlpHead = nn.ModuleList([LayerNorm(self.dim), Linear(self.dim, num_classes), nn.Sigmoid()])
+        self.compute_dtype = None
+
+    def forward(self, images):
+        dt = resolve_compute_dtype(self, images)
+        B, L = images.shape[0], images.shape[1]
+        img = self.patchEmbed(images.reshape(B * L, *images.shape[2:]), dt)
+        for enc in self.visionEncoders:
+            img = enc(img)
+        fused = ops.meanpool_cat(img).view(B, L, self.dim)
+        for enc in self.temporal_encoding:
+            fused = enc(fused)
+        return _head(self.mlpHead, fused).squeeze(dim=1).float()
+
+
+class meant_tweet(nn.Module):
+    """meant/meant_tweet.py:114-167 (with the evident intent of its broken :81, == meant/meant.py:109-120)."""
+
+    def __init__(self, text_dim, price_dim, lag, num_classes, embedding, flash=False, num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.dim = text_dim
+        self.num_heads = num_heads
+        self.embedding = nn.ModuleList([embedding])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.temporal_encoding = nn.ModuleList([temporalEncoder(self.dim, num_heads, lag, norms=False)])
+        self.mlpHead = nn.ModuleList([LayerNorm(self.dim), Linear(self.dim, num_classes), nn.Sigmoid()])
+        self.lag = lag
+        self.compute_dtype = None
+
+    def forward(self, tweets, attention_mask=None):
+        dt = resolve_compute_dtype(self, None)
+        B = tweets.shape[0]
+        words = _embed(self.embedding, tweets.reshape(B * self.lag, tweets.shape[2]), dt)
+        attention_mask = attention_mask.reshape(B * self.lag, attention_mask.shape[2])     # required, as in :150
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask=attention_mask)
+        fused = ops.meanpool_cat(words).view(B, self.lag, self.dim)
+        for enc in self.temporal_encoding:
+            fused = enc(fused)
+        return _head(self.mlpHead, fused).squeeze(dim=1).float()
+
+
+class meant_vqa(nn.Module):
+    """meant/meant_vqa.py:143-234: no lag axis, no cross-attention in the forward that runs; the
+    multimodal_* blocks exist only so that the state_dict matches (:199-200)."""
+
+    def __init__(self, text_dim, image_dim, price_dim, height, width, patch_res, lag, num_classes, embedding, flash=False,
+                 num_heads=8, num_encoders=1, channels=4):
+        super().__init__()
+        self.lag, self.text_dim, self.image_dim = lag, text_dim, image_dim
+        self.dim = text_dim + image_dim
+        self.num_heads = num_heads
+        self.channels = channels
+        self.patch_dim = channels * patch_res * patch_res
+        self.n = int((height * width) / (patch_res ** 2))
+        self.embedding = nn.ModuleList([embedding])
+        self.patchEmbed = _PatchEmbed(self.patch_dim, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.multimodal_embedding = nn.Sequential(nn.Linear(1, self.dim), nn.GELU(), RMSNorm(self.dim), nn.Linear(self.dim, self.dim))
+        self.multimodal_encoding = nn.ModuleList([visionEncoder(self.dim, num_heads, flash=flash)])
+        self.mlpHead = nn.ModuleList([RMSNorm(self.dim), Linear(self.dim, num_classes), nn.Sigmoid()])
+        self.compute_dtype = None
+
+    def forward(self, tweets, images, attention_mask=None):
+        dt = resolve_compute_dtype(self, images)
+        words = _embed(self.embedding, tweets, dt)
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask)
+        img = self.patchEmbed(images, dt)
+        for enc in self.visionEncoders:
+            img = enc(img)
+        fused = ops.meanpool_cat(words, img)
+        return _head(self.mlpHead, fused).float()
+
+
+# single backend: the reference's flash variants are aliases (meant/flash_attention.py, meant/xPosAttention_flash.py)
+flash_attention = attention
+xPosAttention_flash = xPosAttention

@@ -1,0 +1,463 @@
+"""torch.autograd.Function wrappers over the C ABI (include/meant_hip.h).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape.  Every
+numerical operation of the hot path is a call into libmeant_hip.so.  The activation dtype
+(torch.float32 or torch.bfloat16) of the input selects the precision tier; parameters stay
+fp32 (master weights), gradients of parameters are produced in fp32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, F32, BF16, EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SIGMOID
+
+
+# ---------------------------------------------------------------------------------------------
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"meant_amd: activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("meant_amd: this op runs only on an MI355X (HIP) device; got a tensor on "
+                               f"{t.device}.  There is no CPU fallback.")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# weight cache: compute-dtype copy and transposed copy of an fp32 parameter, refreshed when the
+# parameter is updated in place (optimizer step bumps ._version) or replaced.
+class _WeightCache:
+    def __init__(self):
+        self._store = {}
+
+    def get(self, params, dtype: torch.dtype, transposed: bool):
+        """params: tuple of [N_i, K] fp32 parameters, concatenated along N."""
+        key = (tuple(id(p) for p in params), dtype, transposed)
+        ver = tuple((p._version, p.data_ptr()) for p in params)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            w = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], dim=0)
+            w = _c(w)
+            N, K = w.shape
+            sd = F32
+            dd = F32 if dtype == torch.float32 else BF16
+            if transposed:
+                out = torch.empty((K, N), device=w.device, dtype=dtype)
+                check(lib.meant_transpose2d(_p(w), sd, _p(out), dd, N, K, _stream()), "transpose2d")
+            elif dtype == torch.float32:
+                out = w
+            else:
+                out = torch.empty((N, K), device=w.device, dtype=dtype)
+                check(lib.meant_cast(_p(w), sd, _p(out), dd, N * K, _stream()), "cast")
+        self._store[key] = (ver, out)
+        return out
+
+    def clear(self):
+        self._store.clear()
+
+
+weights = _WeightCache()
+
+
+# ---------------------------------------------------------------------------------------------
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, eps, drop_p, seed):
+        _need_gpu(x, scale)
+        x = _c(x)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        rinv = torch.empty(rows, device=x.device, dtype=torch.float32)
+        sc = _c(scale.detach().float())
+        check(lib.meant_rmsnorm_fwd(_p(x), _p(sc), _p(y), _p(rinv), rows, d, eps, drop_p, seed, _dt(x), _stream()),
+              "rmsnorm_fwd")
+        ctx.save_for_backward(x, sc, rinv)
+        ctx.args = (eps, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sc, rinv = ctx.saved_tensors
+        eps, drop_p, seed = ctx.args
+        dy = _c(dy)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dscale = torch.empty(d, device=x.device, dtype=torch.float32)
+        wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+        check(lib.meant_rmsnorm_bwd(_p(dy), _p(x), _p(sc), _p(rinv), _p(dx), _p(dscale), rows, d, eps, drop_p, seed,
+                                    _dt(x), _p(ws), wsb, _stream()), "rmsnorm_bwd")
+        return dx, dscale, None, None, None
+
+
+def rmsnorm(x, scale, eps=1e-8, drop_p=0.0, seed=0):
+    return _RMSNorm.apply(x, scale, float(eps), float(drop_p), int(seed))
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x, gamma, beta)
+        x = _c(x)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+        g, b = _c(gamma.detach().float()), _c(beta.detach().float())
+        check(lib.meant_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(stats), rows, d, eps, _dt(x), _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, g, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, stats = ctx.saved_tensors
+        dy = _c(dy)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dg = torch.empty(d, device=x.device, dtype=torch.float32)
+        db = torch.empty(d, device=x.device, dtype=torch.float32)
+        wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+        check(lib.meant_layernorm_bwd(_p(dy), _p(x), _p(g), _p(stats), _p(dx), _p(dg), _p(db), rows, d, _dt(x), _p(ws), wsb,
+                                      _stream()), "layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+# ---------------------------------------------------------------------------------------------
+def _linear_fwd_raw(x2, w_c, bias_f, residual2, epilogue, want_preact):
+    M, K = x2.shape
+    N = w_c.shape[0]
+    y = torch.empty((M, N), device=x2.device, dtype=x2.dtype)
+    pre = torch.empty_like(y) if want_preact else None
+    check(lib.meant_linear_fwd(_p(x2), x2.stride(0), _p(w_c), _p(bias_f), _p(residual2),
+                               residual2.stride(0) if residual2 is not None else 0, _p(y), N, _p(pre), M, N, K, epilogue,
+                               _dt(x2), _stream()), "linear_fwd")
+    return y, pre
+
+
+def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias):
+    """returns dx2 (or None), dW [sum N_i, K] fp32, db [sum N_i] fp32 or None"""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dx = None
+    if need_dx:
+        wT = weights.get(params, dy2.dtype, True)             # [K, N]
+        dx = torch.empty((M, K), device=dy2.device, dtype=dy2.dtype)
+        check(lib.meant_linear_bwd_dx(_p(dy2), dy2.stride(0), _p(wT), _p(dx), K, M, N, K, _dt(dy2), _stream()), "linear_bwd_dx")
+    dw = torch.zeros((N, K), device=dy2.device, dtype=torch.float32)
+    db = torch.zeros(N, device=dy2.device, dtype=torch.float32) if has_bias else None
+    check(lib.meant_linear_bwd_dw(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(dw), _p(db), M, N, K, _dt(dy2), _stream()),
+          "linear_bwd_dw")
+    return dx, dw, db
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual).  epilogue in {NONE, GELU, SIGMOID} | RESIDUAL."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, epilogue):
+        _need_gpu(x, weight)
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        res2 = _c(residual).view(-1, weight.shape[0]) if residual is not None else None
+        w_c = weights.get((weight,), x.dtype, False)
+        bias_f = _c(bias.detach().float()) if bias is not None else None
+        epi = epilogue | (EPI_RESIDUAL if residual is not None else 0)
+        y, pre = _linear_fwd_raw(x2, w_c, bias_f, res2, epi, bool(epilogue & EPI_GELU))
+        ctx.epilogue = epilogue
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.weight = weight
+        ctx.save_for_backward(x2, pre if (epilogue & EPI_GELU) else (y if (epilogue & EPI_SIGMOID) else None))
+        ctx.in_shape = shp
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, aux = ctx.saved_tensors
+        N = ctx.weight.shape[0]
+        dy2 = _c(dy).view(-1, N)
+        dres = dy if ctx.has_res else None
+        if ctx.epilogue & EPI_GELU:
+            d2 = torch.empty_like(dy2)
+            check(lib.meant_gelu_bwd(_p(dy2), _p(aux), _p(d2), dy2.numel(), _dt(dy2), _stream()), "gelu_bwd")
+            dy2 = d2
+        elif ctx.epilogue & EPI_SIGMOID:
+            d2 = torch.empty_like(dy2)
+            check(lib.meant_sigmoid_bwd(_p(dy2), _p(aux), _p(d2), dy2.numel(), _dt(dy2), _stream()), "sigmoid_bwd")
+            dy2 = d2
+        dx, dw, db = _linear_bwd_raw(dy2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias)
+        return (dx.view(ctx.in_shape) if dx is not None else None), dw, db, dres, None
+
+
+def linear(x, weight, bias=None, residual=None, epilogue=EPI_NONE):
+    return _Linear.apply(x, weight, bias, residual, epilogue)
+
+
+# ---------------------------------------------------------------------------------------------
+class _QKVAttention(torch.autograd.Function):
+    """Fused q/k/v projection + rotary + attention core of meant/attention.py:35-57 and
+    meant/xPosAttention.py:35-63 (up to, not including, multi_mad).
+
+    wq, wk, wv are the parameters the reference calls q, v, k respectively (the k/v naming
+    swap is resolved by the caller).  tables = (qa, qb, ka, kb) float [S, R] or None."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads):
+        _need_gpu(x, wq)
+        G, S, d = x.shape
+        D = wq.shape[0]
+        Dh = D // num_heads
+        x2 = _c(x).view(G * S, d)
+        w_c = weights.get((wq, wk, wv), x.dtype, False)                      # [3D, d]
+        bias_f = torch.cat([bq.detach(), bk.detach(), bv.detach()]).float().contiguous()
+        qkv, _ = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_NONE, False)      # [G*S, 3D]
+        dt = _dt(x)
+        if tables is not None:
+            qa, qb, ka, kb = tables
+            R = qa.shape[1]
+            check(lib.meant_rotary_qk(_p(qkv), G * S, S, num_heads, Dh, R, _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()),
+                  "rotary_qk")
+        o = torch.empty((G * S, D), device=x.device, dtype=x.dtype)
+        lse = torch.empty((G, num_heads, S), device=x.device, dtype=torch.float32)
+        km = _c(key_mask.float()) if key_mask is not None else None
+        scale = 1.0 / math.sqrt(Dh * num_heads)
+        wsb = lib.meant_attn_ws(G, S, num_heads, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=x.device, dtype=torch.uint8)
+        check(lib.meant_attn_fwd(_p(qkv), _p(o), _p(lse), _p(km), G, S, num_heads, Dh, scale, int(causal), dt, _p(ws), wsb,
+                                 _stream()), "attn_fwd")
+        ctx.save_for_backward(x2, qkv, o, lse, km)
+        ctx.params = (wq, wk, wv)
+        ctx.tables = tables
+        ctx.meta = (G, S, d, D, Dh, num_heads, scale, int(causal))
+        return o.view(G, S, D)
+
+    @staticmethod
+    def backward(ctx, do):
+        x2, qkv, o, lse, km = ctx.saved_tensors
+        G, S, d, D, Dh, H, scale, causal = ctx.meta
+        do2 = _c(do).view(G * S, D)
+        dt = _dt(do2)
+        dqkv = torch.empty_like(qkv)
+        wsb = lib.meant_attn_ws(G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=do2.device, dtype=torch.uint8)
+        check(lib.meant_attn_bwd(_p(qkv), _p(o), _p(do2), _p(lse), _p(km), _p(dqkv), G, S, H, Dh, scale, causal, dt, _p(ws), wsb,
+                                 _stream()), "attn_bwd")
+        del ws
+        if ctx.tables is not None:
+            qa, qb, ka, kb = ctx.tables
+            check(lib.meant_rotary_qk(_p(dqkv), G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 1, dt, _stream()),
+                  "rotary_qk(T)")
+        dx, dw, db = _linear_bwd_raw(dqkv, x2, ctx.params, ctx.needs_input_grad[0], True)
+        dwq, dwk, dwv = dw[:D], dw[D:2 * D], dw[2 * D:]
+        dbq, dbk, dbv = db[:D], db[D:2 * D], db[2 * D:]
+        return (dx.view(G, S, d) if dx is not None else None), dwq, dbq, dwk, dbk, dwv, dbv, None, None, None, None
+
+
+def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads):
+    return _QKVAttention.apply(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads)
+
+
+# ---------------------------------------------------------------------------------------------
+class _TemporalAttention(torch.autograd.Function):
+    """meant/temporal.py:34-56 up to multi_mad: q from the last lag step, k/v from all L."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, num_heads):
+        _need_gpu(x, wq)
+        B, L, d = x.shape
+        D = wq.shape[0]
+        Dh = D // num_heads
+        xc = _c(x)
+        x2 = xc.view(B * L, d)
+        xlast = xc[:, L - 1, :]                                                # [B, d] rows strided by L*d
+        wq_c = weights.get((wq,), x.dtype, False)
+        wkv_c = weights.get((wk, wv), x.dtype, False)
+        q, _ = _linear_fwd_raw(xlast, wq_c, _c(bq.detach().float()), None, EPI_NONE, False)            # [B, D]
+        kv, _ = _linear_fwd_raw(x2, wkv_c, torch.cat([bk.detach(), bv.detach()]).float().contiguous(), None, EPI_NONE, False)
+        o = torch.empty((B, D), device=x.device, dtype=x.dtype)
+        p = torch.empty((B, num_heads, L), device=x.device, dtype=torch.float32)
+        scale = 1.0 / math.sqrt(Dh * num_heads)
+        check(lib.meant_temporal_attn_fwd(_p(q), _p(kv), _p(o), _p(p), B, L, num_heads, Dh, scale, _dt(x), _stream()),
+              "temporal_attn_fwd")
+        ctx.save_for_backward(x2, q, kv, p)
+        ctx.params = (wq, wk, wv)
+        ctx.meta = (B, L, d, D, Dh, num_heads, scale)
+        return o.view(B, 1, D)
+
+    @staticmethod
+    def backward(ctx, do):
+        x2, q, kv, p = ctx.saved_tensors
+        B, L, d, D, Dh, H, scale = ctx.meta
+        wq, wk, wv = ctx.params
+        do2 = _c(do).view(B, D)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        check(lib.meant_temporal_attn_bwd(_p(q), _p(kv), _p(p), _p(do2), _p(dq), _p(dkv), B, L, H, Dh, scale, _dt(do2), _stream()),
+              "temporal_attn_bwd")
+        xlast = x2.view(B, L, d)[:, L - 1, :]
+        dxl, dwq, dbq = _linear_bwd_raw(dq, xlast, (wq,), True, True)          # [B, d]
+        dx2, dwkv, dbkv = _linear_bwd_raw(dkv, x2, (wk, wv), True, True)        # [B*L, d]
+        dx = dx2.view(B, L, d)
+        last = dx[:, L - 1, :]
+        tmp = torch.empty((B, d), device=dx.device, dtype=dx.dtype)
+        lc = last.contiguous()
+        check(lib.meant_add(_p(lc), _p(dxl), _p(tmp), B * d, _dt(dx), _stream()), "add")
+        dx[:, L - 1, :] = tmp
+        return dx, dwq, dbq, dwkv[:D], dbkv[:D], dwkv[D:], dbkv[D:], None
+
+
+def temporal_attention(x, wq, bq, wk, bk, wv, bv, num_heads):
+    return _TemporalAttention.apply(x, wq, bq, wk, bk, wv, bv, num_heads)
+
+
+# ---------------------------------------------------------------------------------------------
+class _MeanPoolCat(torch.autograd.Function):
+    """torch.cat([mean_s(a), mean_n(b)], -1) of meant/meant.py:231 (b optional)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        a = _c(a)
+        G, S, da = a.shape
+        db_ = 0
+        if b is not None:
+            b = _c(b)
+            assert b.shape[0] == G and b.dtype == a.dtype
+            db_ = b.shape[2]
+        out = torch.empty((G, da + db_), device=a.device, dtype=a.dtype)
+        check(lib.meant_meanpool_fwd(_p(a), _p(out), da + db_, 0, G, S, da, _dt(a), _stream()), "meanpool_fwd")
+        if b is not None:
+            check(lib.meant_meanpool_fwd(_p(b), _p(out), da + db_, da, G, b.shape[1], db_, _dt(a), _stream()), "meanpool_fwd")
+        ctx.meta = (a.shape, None if b is None else b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sa, sb = ctx.meta
+        dout = _c(dout)
+        ld = dout.shape[1]
+        da = torch.empty(sa, device=dout.device, dtype=dout.dtype)
+        check(lib.meant_meanpool_bwd(_p(dout), ld, 0, _p(da), sa[0], sa[1], sa[2], _dt(dout), _stream()), "meanpool_bwd")
+        db = None
+        if sb is not None:
+            db = torch.empty(sb, device=dout.device, dtype=dout.dtype)
+            check(lib.meant_meanpool_bwd(_p(dout), ld, sa[2], _p(db), sb[0], sb[1], sb[2], _dt(dout), _stream()), "meanpool_bwd")
+        return da, db
+
+
+def meanpool_cat(a, b=None):
+    return _MeanPoolCat.apply(a, b)
+
+
+class _AddRowVec(torch.autograd.Function):
+    """x[b, l, :] + v[0, l, :]  (temp_embedding, meant/meant.py:141-142)."""
+
+    @staticmethod
+    def forward(ctx, x, v):
+        _need_gpu(x, v)
+        x = _c(x)
+        B, L, d = x.shape
+        vf = _c(v.detach().float()).view(L, d)
+        y = torch.empty_like(x)
+        check(lib.meant_add_rowvec(_p(x), _p(vf), _p(y), B * L, d, L, _dt(x), _stream()), "add_rowvec")
+        ctx.meta = (B, L, d, v.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, d, vshape = ctx.meta
+        dy = _c(dy)
+        dv = torch.empty((L, d), device=dy.device, dtype=torch.float32)
+        check(lib.meant_add_rowvec_bwd(_p(dy), _p(dv), B * L, d, L, _dt(dy), _stream()), "add_rowvec_bwd")
+        return dy, dv.view(vshape)
+
+
+def add_rowvec(x, v):
+    return _AddRowVec.apply(x, v)
+
+
+def patchify(images, p: int, dtype: torch.dtype):
+    """einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (meant/meant.py:194); no gradient to pixels."""
+    _need_gpu(images)
+    if images.dtype not in (torch.float32, torch.bfloat16):
+        images = images.float()
+    images = _c(images)
+    G, Cc, Hh, Ww = images.shape
+    n = (Hh // p) * (Ww // p)
+    out = torch.empty((G, n, p * p * Cc), device=images.device, dtype=dtype)
+    check(lib.meant_patchify(_p(images), _dt(images), _p(out), G, Cc, Hh, Ww, p, F32 if dtype == torch.float32 else BF16,
+                             _stream()), "patchify")
+    return out
+
+
+class _Embedding(torch.autograd.Function):
+    """nn.Embedding lookup (meant/meant.py:211) emitting the compute dtype directly."""
+
+    @staticmethod
+    def forward(ctx, ids, table, dtype):
+        _need_gpu(ids, table)
+        ids_c = _c(ids.long())
+        V, d = table.shape
+        n = ids_c.numel()
+        out = torch.empty((*ids.shape, d), device=table.device, dtype=dtype)
+        tf = _c(table.detach().float())
+        check(lib.meant_embedding_fwd(_p(tf), _p(ids_c), _p(out), n, d, V, F32 if dtype == torch.float32 else BF16, _stream()),
+              "embedding_fwd")
+        ctx.save_for_backward(ids_c)
+        ctx.meta = (V, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids_c,) = ctx.saved_tensors
+        V, d = ctx.meta
+        dout = _c(dout)
+        dtab = torch.zeros((V, d), device=dout.device, dtype=torch.float32)
+        check(lib.meant_embedding_bwd(_p(dout), _p(ids_c), _p(dtab), ids_c.numel(), d, V, _dt(dout), _stream()), "embedding_bwd")
+        return None, dtab, None
+
+
+def embedding(ids, table, dtype):
+    return _Embedding.apply(ids, table, dtype)
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """dtype conversion of an activation through the library's cast kernel (no autograd)."""
+    _need_gpu(x)
+    if x.dtype == dtype:
+        return x
+    x = _c(x)
+    out = torch.empty_like(x, dtype=dtype)
+    check(lib.meant_cast(_p(x), _dt(x), _p(out), F32 if dtype == torch.float32 else BF16, x.numel(), _stream()), "cast")
+    return out

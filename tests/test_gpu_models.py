@@ -1,0 +1,152 @@
+"""GPU parity of the model classes (HIP path through the C ABI) against the golden vectors the
+reference produced and against the CPU oracle on the same seeded inputs; both precision tiers."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import DTYPES, IDS, TOL, t, assert_close, assert_grad_close, pair, compare_param_grads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _run_golden(g, hip, inputs, dtype, dev, slices=True):
+    hip.compute_dtype = dtype
+    hip.zero_grad(set_to_none=True)
+    out = hip(*[x.to(dev) for x in inputs])
+    assert out.dtype == torch.float32
+    loss = torch.nn.functional.cross_entropy(out, t(g["target"]).to(dev))
+    loss.backward()
+    tol = TOL[dtype]
+    assert_close(out, t(g["out"]), tol["out"], "out")
+    assert abs(loss.item() - float(g["loss"])) <= tol["out"]
+    params = dict(hip.named_parameters())
+    worst = 0.0
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        a = params[str(name)].grad.double().norm().item()
+        rel = abs(a - ref) / max(ref, 1e-6)
+        worst = max(worst, rel)
+        assert rel <= tol["gnorm"] + 1e-7 / max(ref, 1e-6), (str(name), a, ref)
+    if slices:
+        for key in g.files:
+            if key.startswith("grad__"):
+                p = params[key[6:]]
+                got = p.grad if p.grad.numel() <= 4096 else p.grad[:4]
+                assert_grad_close(got, t(g[key]), tol["gelem"], key)
+    return worst
+
+
+def _mk(cls_name, args, kw, emb, dev):
+    import meant_amd
+    from oracle import meant_oracle as O
+    a = list(args)
+    ref = getattr(O, cls_name)(*(a + ([torch.nn.Embedding(*emb)] if emb else [])), **kw)
+    hip = getattr(meant_amd, cls_name)(*(a + ([torch.nn.Embedding(*emb)] if emb else [])), **kw)
+    return pair(ref, hip, 1234, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_tiny_golden(golden, dev, dtype):
+    g = golden("meant_tiny")
+    _, hip = _mk("meant", (128, 128, 4, 32, 32, 16, 3, 2), dict(num_heads=2, num_encoders=1, channels=4), (100, 128), dev)
+    _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), dtype, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_tiny_two_layers_golden(golden, dev, dtype):
+    g = golden("meant_tiny_e2")
+    _, hip = _mk("meant", (128, 192, 4, 32, 48, 16, 2, 3), dict(num_heads=2, num_encoders=2, channels=4), (50, 128), dev)
+    _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), dtype, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_tweet_c1_golden(golden, dev, dtype):
+    g = golden("meant_tweet_c1")
+    _, hip = _mk("meant_tweet", (128, 4, 1, 2), dict(num_heads=2, num_encoders=1), (1000, 128), dev)
+    _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_mask"])), dtype, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_vision_tiny_golden(golden, dev, dtype):
+    g = golden("meant_vision_tiny")
+    _, hip = _mk("meant_vision", (128, 4, 32, 32, 16, 3, 2), dict(num_heads=2, num_encoders=1, channels=4), None, dev)
+    _run_golden(g, hip, (t(g["in_images"]),), dtype, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_vqa_tiny_golden(golden, dev, dtype):
+    g = golden("meant_vqa_tiny")
+    _, hip = _mk("meant_vqa", (128, 128, 4, 32, 32, 16, 1, 7), dict(num_heads=2, num_encoders=1, channels=4), (100, 128), dev)
+    _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), dtype, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_vision_c2_golden(golden, dev, dtype):
+    """BASELINE config 2: meant_vision lag=1, 224x224 p=16, d=768, 12 heads."""
+    g = golden("meant_vision_c2")
+    r = np.random.RandomState(102)
+    img = t(r.standard_normal((2, 1, 4, 224, 224)).astype("float32"))
+    _, hip = _mk("meant_vision", (768, 4, 224, 224, 16, 1, 2), dict(num_heads=12, num_encoders=1, channels=4), None, dev)
+    _run_golden(g, hip, (img,), dtype, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_full_c3_golden(golden, dev, dtype):
+    """BASELINE config 3 at full dims: lag 12, d 768, 12 heads, S 512, 224x224 (B=2, V=2000)."""
+    g = golden("meant_full_c3")
+    r = np.random.RandomState(99)
+    ids = t(r.randint(0, 2000, (2, 12, 512)).astype("int64"))
+    img = t(r.standard_normal((2, 12, 4, 224, 224)).astype("float32"))
+    mask = torch.ones(2, 12, 512)
+    mask[1, :, 400:] = 0
+    _, hip = _mk("meant", (768, 768, 4, 224, 224, 16, 12, 2), dict(num_heads=12, num_encoders=1), (2000, 768), dev)
+    worst = _run_golden(g, hip, (ids, img, mask), dtype, dev)
+    print(f"full C3 [{dtype}]: worst grad-norm rel err {worst:.3e}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_model_vs_oracle_ragged(dev, dtype):
+    """oracle comparison on shapes no fixture covers: ragged token / patch counts, 3 lag steps, batch 5"""
+    ref, hip = _mk("meant", (128, 128, 4, 48, 80, 16, 3, 4), dict(num_heads=2, num_encoders=1, channels=4), (77, 128), dev)
+    r = np.random.RandomState(7)
+    ids = t(r.randint(0, 77, (5, 3, 41)).astype("int64"))
+    img = t(r.standard_normal((5, 3, 4, 48, 80)).astype("float32"))
+    mask = torch.ones(5, 3, 41)
+    mask[0, :, 30:] = 0
+    mask[3, 1, 1:] = 0
+    tgt = torch.tensor([0, 3, 1, 2, 2])
+    out_r = ref(ids, img, mask)
+    torch.nn.functional.cross_entropy(out_r, tgt).backward()
+    hip.compute_dtype = dtype
+    out = hip(ids.to(dev), img.to(dev), mask.to(dev))
+    torch.nn.functional.cross_entropy(out, tgt.to(dev)).backward()
+    assert_close(out, out_r, TOL[dtype]["out"], "out")
+    compare_param_grads(ref, hip, dtype, "ragged")
+
+
+def test_autocast_selects_bf16_and_state_dict_roundtrip(dev):
+    import meant_amd
+    m = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2).to(dev).eval()
+    ids = torch.randint(0, 100, (2, 3, 16), device=dev)
+    img = torch.randn(2, 3, 4, 32, 32, device=dev)
+    mask = torch.ones(2, 3, 16, device=dev)
+    o32 = m(ids, img, mask)
+    with torch.autocast("cuda", dtype=torch.float16):          # what in_loop_train.py:215 does
+        o16 = m(ids, img.half(), attention_mask=mask)
+    assert o16.dtype == torch.float32 and (o16 - o32).abs().max().item() < 1e-2
+    assert (o16 - o32).abs().max().item() > 0                  # really took the bf16 path
+    sd = m.state_dict()
+    m2 = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2).to(dev).eval()
+    m2.load_state_dict(sd)
+    assert torch.equal(m2(ids, img, mask), o32)
+    import io, pickle
+    buf = io.BytesIO()
+    torch.save(m, buf)                                          # whole-module pickle, in_loop_train.py:331
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert torch.equal(m3(ids, img, mask), o32)

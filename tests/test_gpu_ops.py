@@ -1,0 +1,317 @@
+"""GPU parity of each HIP op (through the C ABI) against the CPU oracle / golden vectors."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import DTYPES, IDS, TOL, t, assert_close, assert_grad_close, pair, compare_param_grads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def M():
+    import meant_amd
+    return meant_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import meant_oracle
+    return meant_oracle
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,d", [(51, 768), (7, 1536), (130, 128), (3, 256), (1000, 768)])
+def test_rmsnorm(M, O, dev, golden, dtype, rows, d):
+    rs = np.random.RandomState(rows + d)
+    x = t(rs.standard_normal((rows, d)).astype("float32"))
+    g = t((1 + 0.1 * rs.standard_normal(d)).astype("float32"))
+    dy = t(rs.standard_normal((rows, d)).astype("float32"))
+    ref = O.RMSNorm(d)
+    hip = M.RMSNorm(d).to(dev)
+    with torch.no_grad():
+        ref.scale.copy_(g)
+        hip.scale.copy_(g)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    yr.backward(dy)
+    xh = x.to(dev).to(dtype).requires_grad_()
+    yh = hip(xh)
+    yh.backward(dy.to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert yh.dtype == dtype
+    assert_close(yh, yr, tol["out"] * 4, "y")
+    assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+    assert_grad_close(hip.scale.grad, ref.scale.grad, tol["gelem"], "dscale")
+
+
+def test_rmsnorm_golden(M, dev, golden):
+    g = golden("rmsnorm_768")
+    hip = M.RMSNorm(768).to(dev)
+    with torch.no_grad():
+        hip.scale.copy_(t(g["scale"]))
+    x = t(g["x"]).to(dev).requires_grad_()
+    y = hip(x)
+    y.backward(t(g["dy"]).to(dev))
+    assert_close(y, t(g["y"]), 1e-5, "y")
+    assert_close(x.grad, t(g["dx"]), 1e-5, "dx")
+    assert_grad_close(hip.scale.grad, t(g["dscale"]), 1e-4, "dscale")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_rmsnorm_dropout_is_consistent(M, dev, dtype):
+    """train-mode fused dropout: forward mask == backward mask, keep-rate ~ 1-p, scaling 1/(1-p)."""
+    from meant_amd import ops
+    x = torch.randn(256, 768, device=dev).to(dtype).requires_grad_()
+    scale = torch.ones(768, device=dev, requires_grad=True)
+    y = ops.rmsnorm(x, scale, 1e-8, 0.5, 1234)
+    y0 = ops.rmsnorm(x, scale, 1e-8, 0.0, 0)
+    kept = (y != 0)
+    rate = kept.float().mean().item()
+    assert 0.48 < rate < 0.52
+    assert_close(y[kept], 2 * y0[kept], 2e-2 if dtype == torch.bfloat16 else 1e-5, "scaled")
+    y.backward(torch.ones_like(y))
+    # gradient flows only through kept elements: d/dscale_j = sum_rows mask * 2 * x_j * r
+    gs = (kept.float() * 2 * (y0.detach().float())).sum(0)
+    assert_grad_close(scale.grad, gs, 2e-2 if dtype == torch.bfloat16 else 1e-4, "dscale")
+    y2 = ops.rmsnorm(x, scale, 1e-8, 0.5, 1234)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_layernorm(M, dev, dtype):
+    rs = np.random.RandomState(5)
+    x = t(rs.standard_normal((9, 768)).astype("float32"))
+    dy = t(rs.standard_normal((9, 768)).astype("float32"))
+    ref = torch.nn.LayerNorm(768)
+    hip = M.LayerNorm(768)
+    with torch.no_grad():
+        ref.weight.copy_(t((1 + 0.1 * rs.standard_normal(768)).astype("float32")))
+        ref.bias.copy_(t((0.1 * rs.standard_normal(768)).astype("float32")))
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    xr = x.clone().requires_grad_()
+    ref(xr).backward(dy)
+    xh = x.to(dev).to(dtype).requires_grad_()
+    yh = hip(xh)
+    yh.backward(dy.to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert_close(yh, ref(x), tol["out"] * 4, "y")
+    assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+    assert_grad_close(hip.weight.grad, ref.weight.grad, tol["gelem"], "dgamma")
+    assert_grad_close(hip.bias.grad, ref.bias.grad, tol["gelem"], "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("M_,N,K", [(300, 768, 768), (64, 2304, 768), (1000, 128, 1024), (5, 2, 1536), (257, 3129, 256),
+                                     (128, 128, 128), (4097, 768, 768)])
+@pytest.mark.parametrize("epi", ["none", "gelu", "residual", "sigmoid"])
+def test_linear(M, dev, dtype, M_, N, K, epi):
+    from meant_amd import ops
+    from meant_amd._lib import EPI_NONE, EPI_GELU, EPI_SIGMOID
+    if epi != "none" and (M_, N, K) not in [(300, 768, 768), (5, 2, 1536), (1000, 128, 1024)]:
+        pytest.skip("epilogues are covered on three shapes")
+    rs = np.random.RandomState(M_ + N)
+    x = t(rs.standard_normal((M_, K)).astype("float32"))
+    w = t((rs.standard_normal((N, K)) / math.sqrt(K)).astype("float32"))
+    b = t((0.1 * rs.standard_normal(N)).astype("float32"))
+    res = t(rs.standard_normal((M_, N)).astype("float32"))
+    dy = t(rs.standard_normal((M_, N)).astype("float32"))
+    # reference in fp32 on CPU, on the dtype-rounded inputs
+    xq, wq, resq, dyq = [v.to(dtype).float() for v in (x, w, res, dy)]
+    xr, wr, br, rr = xq.clone().requires_grad_(), wq.clone().requires_grad_(), b.clone().requires_grad_(), resq.clone().requires_grad_()
+    yr = torch.nn.functional.linear(xr, wr, br)
+    if epi == "gelu":
+        yr = torch.nn.functional.gelu(yr)
+    elif epi == "sigmoid":
+        yr = torch.sigmoid(yr)
+    elif epi == "residual":
+        yr = yr + rr
+    yr.backward(dyq)
+    xh = x.to(dev).to(dtype).requires_grad_()
+    wh = wq.to(dev).requires_grad_()          # fp32 master weights that are exactly representable in `dtype`
+    bh = b.to(dev).requires_grad_()
+    rh = res.to(dev).to(dtype).requires_grad_()
+    e = {"none": EPI_NONE, "gelu": EPI_GELU, "sigmoid": EPI_SIGMOID, "residual": EPI_NONE}[epi]
+    yh = ops.linear(xh, wh, bh, rh if epi == "residual" else None, e)
+    yh.backward(dy.to(dev).to(dtype))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert yh.dtype == dtype and yh.shape == (M_, N)
+    assert_close(yh, yr, tol * max(1.0, yr.abs().max().item()) , "y")
+    gt = 1e-3 if dtype == torch.float32 else 2e-2
+    assert_grad_close(xh.grad, xr.grad, gt, "dx")
+    assert_grad_close(wh.grad, wr.grad, gt, "dw")
+    assert_grad_close(bh.grad, br.grad, gt, "db")
+    if epi == "residual":
+        assert_grad_close(rh.grad, rr.grad, gt, "dres")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_rotary_against_golden(M, dev, golden, dtype):
+    """rotary kernel on a packed q|k|v buffer vs vectors produced by the reference's rotary library"""
+    from meant_amd import ops
+    from meant_amd._lib import lib, check
+    g = golden("rotary_xpos48")
+    rot = M.RotaryEmbedding(dim=48, use_xpos=True)
+    for S in (16, 64, 512):
+        q, k = t(g[f"q{S}"]), t(g[f"k{S}"])                      # [1, 2, S, 64] (b h s dh)
+        H, Dh = 2, 64
+        qkv = torch.zeros(S, 3 * H * Dh)
+        qkv[:, : H * Dh] = q[0].permute(1, 0, 2).reshape(S, H * Dh)
+        qkv[:, H * Dh: 2 * H * Dh] = k[0].permute(1, 0, 2).reshape(S, H * Dh)
+        qkv[:, 2 * H * Dh:] = 7.0
+        buf = qkv.to(dev).to(dtype).contiguous()
+        orig = buf.clone()
+        qa, qb, ka, kb = rot.tables(S, dev)
+        dt = 0 if dtype == torch.float32 else 1
+        check(lib.meant_rotary_qk(buf.data_ptr(), S, S, H, Dh, 48, qa.data_ptr(), qb.data_ptr(), ka.data_ptr(), kb.data_ptr(),
+                                  0, dt, torch.cuda.current_stream().cuda_stream))
+        rq = buf[:, : H * Dh].float().cpu().view(S, H, Dh).permute(1, 0, 2)
+        rk = buf[:, H * Dh: 2 * H * Dh].float().cpu().view(S, H, Dh).permute(1, 0, 2)
+        tol = 2e-5 if dtype == torch.float32 else 4e-2
+        assert_close(rq, t(g[f"rq{S}"])[0], tol, f"q S={S}")
+        assert_close(rk, t(g[f"rk{S}"])[0], tol, f"k S={S}")
+        assert torch.equal(buf[:, 2 * H * Dh:], orig[:, 2 * H * Dh:])            # v untouched
+        # adjoint: <R x, y> == <x, R^T y>
+        y = torch.randn_like(buf.float()).to(dtype)
+        yt = y.clone()
+        check(lib.meant_rotary_qk(yt.data_ptr(), S, S, H, Dh, 48, qa.data_ptr(), qb.data_ptr(), ka.data_ptr(), kb.data_ptr(),
+                                  1, dt, torch.cuda.current_stream().cuda_stream))
+        lhs = (buf.float() * y.float())[:, : 2 * H * Dh].sum().item()
+        rhs = (orig.float() * yt.float())[:, : 2 * H * Dh].sum().item()
+        assert abs(lhs - rhs) <= (1e-3 if dtype == torch.float32 else 0.05) * max(1.0, abs(lhs))
+
+
+def _attn_pair(M, O, kind, H, d, dev):
+    if kind == "pixel":
+        ref = O.attention(H, d, O.RotaryTable(math.floor(d / H / 2), "pixel"))
+        hip = M.attention(H, d, M.RotaryEmbedding(dim=math.floor(d / H / 2), freqs_for="pixel"))
+    else:
+        ref = O.xPosAttention(H, d, O.RotaryTable(48, "lang", use_xpos=True))
+        hip = M.xPosAttention(H, d, M.RotaryEmbedding(dim=48, use_xpos=True))
+    return pair(ref, hip, 4321, dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("name,kind", [("attention_h2_d128_n196", "pixel"), ("xposattention_h2_d128_s80", "xpos"),
+                                       ("xposattention_h2_d128_s512", "xpos")])
+def test_attention_modules_golden(M, O, dev, golden, dtype, name, kind):
+    g = golden(name)
+    ref, hip = _attn_pair(M, O, kind, 2, 128, dev)
+    x = t(g["x"]).to(dev).to(dtype).requires_grad_()
+    args = (t(g["mask"]).to(dev),) if kind == "xpos" else ()
+    y = hip(x, *args)
+    y.backward(t(g["dy"]).to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert_close(y, t(g["y"]), tol["out"] * (1 if dtype == torch.float32 else 4), "y")
+    assert_grad_close(x.grad, t(g["dx"]), tol["gelem"], "dx")
+    params = dict(hip.named_parameters())
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        p = params[str(nm)]
+        a = p.grad.double().norm().item()
+        assert abs(a - refn) <= tol["gnorm"] * max(refn, 1e-4), (nm, a, refn)
+        ga = t(g["grad__" + str(nm)])
+        got = p.grad if p.grad.numel() <= 4096 else p.grad[:4]
+        assert_grad_close(got, ga, tol["gelem"] * 2, str(nm))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("kind,G,S,H,d", [("pixel", 3, 196, 12, 768), ("xpos", 2, 512, 12, 768), ("xpos", 5, 64, 2, 128),
+                                          ("pixel", 2, 4, 2, 128), ("xpos", 3, 100, 4, 256), ("xpos", 2, 1, 2, 128),
+                                          ("pixel", 1, 300, 2, 128)])
+def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
+    """real head geometry incl. ragged lengths (not multiples of any tile), S=1, fully padded rows"""
+    ref, hip = _attn_pair(M, O, kind, H, d, dev)
+    rs = np.random.RandomState(S + d)
+    x = t(rs.standard_normal((G, S, d)).astype("float32"))
+    dy = t(rs.standard_normal((G, S, d)).astype("float32"))
+    mask = torch.ones(G, S)
+    if kind == "xpos" and S > 1:
+        mask[0, S // 2:] = 0
+        mask[G - 1, :] = 0           # everything padded: softmax falls back to uniform over the causal window
+    xq, dyq = x.to(dtype).float(), dy.to(dtype).float()
+    xr = xq.clone().requires_grad_()
+    yr = ref(xr, mask) if kind == "xpos" else ref(xr)
+    yr.backward(dyq)
+    xh = x.to(dev).to(dtype).requires_grad_()
+    yh = hip(xh, mask.to(dev)) if kind == "xpos" else hip(xh)
+    yh.backward(dy.to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert_close(yh, yr, tol["out"] * (1 if dtype == torch.float32 else 4), "y")
+    assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+    compare_param_grads(ref, hip, dtype, kind)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_temporal_golden(M, O, dev, golden, dtype):
+    g = golden("temporal_h12_d1536_l12")
+    ref, hip = pair(O.temporal(12, 1536), M.temporal(12, 1536), 4321, dev)
+    x = t(g["x"]).to(dev).to(dtype).requires_grad_()
+    y = hip(x)
+    y.backward(t(g["dy"]).to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert y.shape == (3, 1, 1536)
+    assert_close(y, t(g["y"]), tol["out"] * (1 if dtype == torch.float32 else 4), "y")
+    assert_grad_close(x.grad, t(g["dx"]), tol["gelem"], "dx")
+    params = dict(hip.named_parameters())
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        a = params[str(nm)].grad.double().norm().item()
+        assert abs(a - refn) <= tol["gnorm"] * max(refn, 1e-4), (nm, a, refn)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meanpool_patchify_embedding_rowvec(M, O, dev, dtype):
+    from meant_amd import ops
+    rs = np.random.RandomState(11)
+    a = t(rs.standard_normal((6, 37, 128)).astype("float32"))
+    b = t(rs.standard_normal((6, 196, 256)).astype("float32"))
+    ah, bh = a.to(dev).to(dtype).requires_grad_(), b.to(dev).to(dtype).requires_grad_()
+    out = ops.meanpool_cat(ah, bh)
+    ref = torch.cat((a.to(dtype).float().mean(1), b.to(dtype).float().mean(1)), dim=1)
+    assert_close(out, ref, 1e-5 if dtype == torch.float32 else 1e-2, "meanpool")
+    w = torch.randn_like(out.float())
+    out.backward(w.to(dtype))
+    assert_close(ah.grad, (w[:, :128].to(dtype).float().cpu() / 37)[:, None, :].expand(6, 37, 128), 1e-6 if dtype == torch.float32 else 1e-3, "d meanpool a")
+    assert_close(bh.grad, (w[:, 128:].to(dtype).float().cpu() / 196)[:, None, :].expand(6, 196, 256), 1e-6 if dtype == torch.float32 else 1e-3, "d meanpool b")
+    # patchify (exact data movement)
+    img = t(rs.standard_normal((3, 4, 32, 48)).astype("float32"))
+    got = ops.patchify(img.to(dev), 16, dtype)
+    assert_close(got, O.patchify(img, 16).to(dtype).float(), 0.0, "patchify")
+    # embedding gather + scatter-add
+    table = torch.randn(50, 128)
+    ids = torch.randint(0, 50, (4, 9))
+    th = table.to(dev).requires_grad_()
+    e = ops.embedding(ids.to(dev), th, dtype)
+    assert_close(e, table[ids].to(dtype).float(), 0.0, "embedding")
+    ge = torch.randn(4, 9, 128)
+    e.backward(ge.to(dev).to(dtype))
+    tr = table.clone().requires_grad_()
+    torch.nn.functional.embedding(ids, tr).backward(ge.to(dtype).float())
+    assert_close(th.grad, tr.grad, 1e-5 if dtype == torch.float32 else 1e-2, "d embedding")
+    # temp-embedding add
+    x = torch.randn(5, 3, 256)
+    v = torch.randn(1, 3, 256)
+    xh, vh = x.to(dev).to(dtype).requires_grad_(), v.to(dev).requires_grad_()
+    y = ops.add_rowvec(xh, vh)
+    assert_close(y, x.to(dtype).float() + v, 1e-6 if dtype == torch.float32 else 2e-2, "add_rowvec")
+    gy = torch.randn(5, 3, 256)
+    y.backward(gy.to(dev).to(dtype))
+    assert_close(vh.grad, gy.to(dtype).float().sum(0, keepdim=True), 1e-5 if dtype == torch.float32 else 1e-2, "d temp_embedding")
+
+
+def test_errors_are_loud(M, dev):
+    from meant_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.rmsnorm(torch.randn(4, 768), torch.ones(768))            # CPU tensor: no fallback
+    with pytest.raises(M.MeantHipError):
+        ops.rmsnorm(torch.randn(4, 100, device=dev), torch.ones(100, device=dev))   # d % 8 != 0
+    with pytest.raises(TypeError):
+        ops.rmsnorm(torch.randn(4, 768, device=dev).half(), torch.ones(768, device=dev))
