@@ -7,7 +7,7 @@
 
 namespace {
 
-// one wave per score row.  mode 0: compute lse, write P.  mode 1: lse given, write P = exp(v - lse).
+// one wave per score row.  mode 0: compute (max, log-sum), write P.  mode 1: stats given, write P.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ sc, float* __restrict__ lse,
                                                             const float* __restrict__ key_mask, int64_t g0, int64_t nrows,
                                                             int S, int H, int causal, int mode) {
@@ -26,8 +26,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
     if (km) v += (1.0f - km[j]) * -1e9f;
     m = fmaxf(m, v);
   }
-  float l;
-  float* lp = lse + ((g * H + gh % H) * (int64_t)S + i);
+  // the row statistics are kept as the pair (max, log-sum): with the reference's additive -1e9 padding
+  // term a fully padded row has max ~ -1e9, where a single float max+log(sum) would lose the log(sum).
+  float logl;
+  float* lp = lse + ((g * H + gh % H) * (int64_t)S + i) * 2;
   if (mode == 0) {
     m = wave_max(m);
     float s = 0.f;
@@ -37,17 +39,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
       s += __expf(v - m);
     }
     s = wave_sum(s);
-    l = m + __logf(s);
-    if (lane == 0) *lp = l;
+    logl = __logf(s);
+    if (lane == 0) { lp[0] = m; lp[1] = logl; }
   } else {
-    l = *lp;
+    m = lp[0];
+    logl = lp[1];
   }
   for (int j = lane; j < S; j += 64) {
     float v = 0.f;
     if (j < jend) {
       v = p[j];
       if (km) v += (1.0f - km[j]) * -1e9f;
-      v = __expf(v - l);
+      v = __expf((v - m) - logl);
     }
     p[j] = v;
   }

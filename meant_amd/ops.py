@@ -249,7 +249,7 @@ class _QKVAttention(torch.autograd.Function):
             check(lib.meant_rotary_qk(_p(qkv), G * S, S, num_heads, Dh, R, _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()),
                   "rotary_qk")
         o = torch.empty((G * S, D), device=x.device, dtype=x.dtype)
-        lse = torch.empty((G, num_heads, S), device=x.device, dtype=torch.float32)
+        lse = torch.empty((G, num_heads, S, 2), device=x.device, dtype=torch.float32)
         km = _c(key_mask.float()) if key_mask is not None else None
         scale = 1.0 / math.sqrt(Dh * num_heads)
         wsb = lib.meant_attn_ws(G, S, num_heads, Dh, dt)
