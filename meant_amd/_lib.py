@@ -37,8 +37,8 @@ SIGNATURES = {
     "meant_temporal_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
     "meant_temporal_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
     "meant_patchify": (_i, [_p, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
-    "meant_meanpool_fwd": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p]),
-    "meant_meanpool_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_meanpool_fwd": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i, _p]),
+    "meant_meanpool_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _p]),
     "meant_add_rowvec": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "meant_add_rowvec_bwd": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "meant_gelu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),

@@ -1,6 +1,13 @@
 // extern "C" entry points for Linear and the attention core: argument checks + dtype dispatch.
 #include "internal.h"
 
+// preconditions of the MFMA bf16 NT kernel (global_load_lds moves 16-byte pieces; vector epilogue stores)
+static bool bf16_nt_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, const void* r,
+                       int64_t ldr, int64_t K) {
+  (void)c; (void)ldc; (void)r; (void)ldr;
+  return (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && meant_aligned16(a) && meant_aligned16(b);
+}
+
 extern "C" int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual, int64_t ldr,
                                 void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K, int epilogue, int dtype,
                                 void* stream) {
@@ -11,10 +18,21 @@ extern "C" int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const
   if (dtype == MEANT_F32) {
     MEANT_REQUIRE(!residual || ldr == ldy, MEANT_ERR_UNSUPPORTED, "linear_fwd(f32): residual stride must equal output stride");
     GemmF32Args a{};
-    a.A = (const float*)x; a.B = (const float*)w; a.C = (float*)y;
+    a.A = x; a.B = w; a.C = y;
     a.M = M; a.N = N; a.K = K; a.nb1 = 1; a.nb2 = 1;
     a.sA[2] = ldx; a.sA[3] = 1; a.sB[2] = 1; a.sB[3] = K; a.sC[2] = ldy; a.sC[3] = 1;
-    a.alpha = 1.f; a.bias = bias; a.residual = (const float*)residual; a.preact = (float*)preact; a.epilogue = epilogue;
+    a.alpha = 1.f; a.bias = bias; a.residual = residual; a.preact = preact; a.epilogue = epilogue;
+    return gemm_f32_launch(a, (hipStream_t)stream);
+  }
+  if (dtype == MEANT_BF16 && !bf16_nt_ok(x, ldx, w, K, y, ldy, residual, ldr, K)) {
+    // odd shapes (K not a multiple of 64, unaligned rows: e.g. the class head): exact-f32 generic path on bf16 storage
+    MEANT_REQUIRE(!residual || ldr == ldy, MEANT_ERR_UNSUPPORTED, "linear_fwd(bf16 generic): residual stride must equal output stride");
+    GemmF32Args a{};
+    a.in_dtype = MEANT_BF16; a.out_dtype = MEANT_BF16;
+    a.A = x; a.B = w; a.C = y;
+    a.M = M; a.N = N; a.K = K; a.nb1 = 1; a.nb2 = 1;
+    a.sA[2] = ldx; a.sA[3] = 1; a.sB[2] = 1; a.sB[3] = K; a.sC[2] = ldy; a.sC[3] = 1;
+    a.alpha = 1.f; a.bias = bias; a.residual = residual; a.preact = preact; a.epilogue = epilogue;
     return gemm_f32_launch(a, (hipStream_t)stream);
   }
   if (dtype == MEANT_BF16) {
@@ -34,7 +52,16 @@ extern "C" int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT,
   MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && lddx >= K, MEANT_ERR_ARG, "linear_bwd_dx: bad shape");
   if (dtype == MEANT_F32) {
     GemmF32Args a{};
-    a.A = (const float*)dy; a.B = (const float*)wT; a.C = (float*)dx;
+    a.A = dy; a.B = wT; a.C = dx;
+    a.M = M; a.N = K; a.K = N; a.nb1 = 1; a.nb2 = 1;
+    a.sA[2] = lddy; a.sA[3] = 1; a.sB[2] = 1; a.sB[3] = N; a.sC[2] = lddx; a.sC[3] = 1;
+    a.alpha = 1.f;
+    return gemm_f32_launch(a, (hipStream_t)stream);
+  }
+  if (dtype == MEANT_BF16 && !bf16_nt_ok(dy, lddy, wT, N, dx, lddx, nullptr, 0, N)) {
+    GemmF32Args a{};
+    a.in_dtype = MEANT_BF16; a.out_dtype = MEANT_BF16;
+    a.A = dy; a.B = wT; a.C = dx;
     a.M = M; a.N = K; a.K = N; a.nb1 = 1; a.nb2 = 1;
     a.sA[2] = lddy; a.sA[3] = 1; a.sB[2] = 1; a.sB[3] = N; a.sC[2] = lddx; a.sC[3] = 1;
     a.alpha = 1.f;
@@ -56,13 +83,25 @@ extern "C" int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, 
   MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K, MEANT_ERR_ARG, "linear_bwd_dw: bad shape");
   if (dtype == MEANT_F32) {
     GemmF32Args a{};
-    a.A = (const float*)dy; a.B = (const float*)x; a.C = dw;
+    a.A = dy; a.B = x; a.C = dw;
     a.M = N; a.N = K; a.K = M; a.nb1 = 1; a.nb2 = 1;
     a.sA[2] = 1; a.sA[3] = lddy; a.sB[2] = ldx; a.sB[3] = 1; a.sC[2] = K; a.sC[3] = 1;
     a.alpha = 1.f; a.accumulate = 1;
     int rc = gemm_f32_launch(a, (hipStream_t)stream);
     if (rc) return rc;
     if (dbias) return colsum_launch(dy, lddy, dbias, M, N, MEANT_F32, 1, (hipStream_t)stream);
+    return MEANT_OK;
+  }
+  if (dtype == MEANT_BF16 && (N < 8 || K < 8 || (lddy & 7) || (ldx & 7) || !meant_aligned16(dy) || !meant_aligned16(x))) {
+    GemmF32Args a{};
+    a.in_dtype = MEANT_BF16; a.out_dtype = MEANT_F32;
+    a.A = dy; a.B = x; a.C = dw;
+    a.M = N; a.N = K; a.K = M; a.nb1 = 1; a.nb2 = 1;
+    a.sA[2] = 1; a.sA[3] = lddy; a.sB[2] = ldx; a.sB[3] = 1; a.sC[2] = K; a.sC[3] = 1;
+    a.alpha = 1.f; a.accumulate = 1;
+    int rc = gemm_f32_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    if (dbias) return colsum_launch(dy, lddy, dbias, M, N, MEANT_BF16, 1, (hipStream_t)stream);
     return MEANT_OK;
   }
   if (dtype == MEANT_BF16)
@@ -88,7 +127,7 @@ extern "C" int meant_attn_fwd(const void* qkv, void* o, float* lse, const float*
   if (dtype == MEANT_F32)
     return attn_f32_fwd((const float*)qkv, (float*)o, lse, key_mask, G, S, H, Dh, scale, causal, workspace, workspace_bytes, (hipStream_t)stream);
   if (dtype == MEANT_BF16)
-    return attn_bf16_fwd((const bf16*)qkv, (bf16*)o, lse, key_mask, G, S, H, Dh, scale, causal, (hipStream_t)stream);
+    return attn_bf16_fwd((const bf16*)qkv, (bf16*)o, lse, key_mask, G, S, H, Dh, scale, causal, workspace, workspace_bytes, (hipStream_t)stream);
   meant_set_error("attn_fwd: unknown dtype %d", dtype);
   return MEANT_ERR_ARG;
 }

@@ -1,0 +1,581 @@
+// K3/K4: fused (flash-style) attention core for the bf16 tier, head dim 64, gfx950 MFMA 32x32x16.
+// Replaces the reference's eager scores->softmax->PV chain (meant/attention.py:43-57,
+// meant/xPosAttention.py:41-63) and its flash-attn dependency (meant/flash_attention.py:42,
+// meant/xPosAttention_flash.py:40) with eager semantics: scale 1/sqrt(dim), causal -inf, additive
+// (1-mask)*-1e9 key padding applied to the fp32 score before the softmax.
+//
+// Layout: q|k|v packed [G*S, 3*H*64] (rotary already applied), heads are 64-column slices; O [G*S, H*64].
+//
+// Forward / dQ kernels ("query on the lane"): workgroup = 4 waves x 32 queries; K/V tiles of 64 keys
+//   stream HBM -> LDS by global_load_lds (double-buffered, one barrier per tile).
+//   S^T = K Q^T is computed with the KEY as the MFMA row, so a lane owns one query column: softmax
+//   statistics are per-lane scalars, and the exponentiated accumulator is directly the B operand of the
+//   next product (O^T += V^T P^T, dQ^T += K^T dS^T) -- no LDS round trip for P.  The V^T / K^T operands come
+//   from ds_read_b64_tr_b16 (hardware transpose) of the row-major tiles.
+// dK/dV kernel ("key on the lane"): workgroup = 4 waves x 32 keys, K and V fragments live in registers,
+//   Q / dO tiles of 64 queries stream through LDS and are read by rows (S, dP) and transposed (dV^T, dK^T).
+//   dQ is produced by its own pass (recomputing S and dP) instead of float atomics: deterministic, and
+//   the atomic rate (1.3 TB/s) would otherwise bound the kernel.
+// One LDS image serves row reads and transposed reads: 128-byte rows, 16-byte chunk c of row r stored at
+//   slot c ^ f(r), f(r) = ((r&2)<<1) | ((r>>2)&3)  (conflict-free for both access shapes).
+// Row statistics are the pair (m, log l): see include/meant_hip.h.
+// Roofline: per (g,h) the kernel moves 4*S*64*2 bytes and does 4*S*S*64 FLOPs (fwd); at S=512 / 196 the
+// arithmetic intensity (256 / 98 FLOP/B) is below the machine balance, and the exp() work per score keeps
+// the VALU, not the MFMA, on the critical path for Dh=64.
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+constexpr int DH = 64;
+constexpr int KV_TILE = 64;
+constexpr int TILE_B = KV_TILE * DH * 2;          // 8 KiB
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int swz(int r) { return ((r & 2) << 1) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+// stage a [64 rows][64 cols] bf16 tile: rows row0.. (clamped to nrows-1) of a matrix with row stride ld.
+// 8 pieces of 1 KiB (8 rows each); wave w issues pieces 2w, 2w+1.
+__device__ __forceinline__ void stage64(const bf16* __restrict__ g, int64_t ld, int row0, int nrows, char* tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave * 2 + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz(r);
+    int gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;
+    glds16(g + (int64_t)gr * ld + c * 8, tile + piece * 1024);
+  }
+}
+
+// A/B fragment of mfma_32x32x16 from a row-major tile: lane (r = lane&31, h = lane>>5) gets
+// tile[row0 + r][16*ks + 8h .. +7]
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row0, int ks, int lane) {
+  const int r = row0 + (lane & 31);
+  const int c = 2 * ks + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ swz(r)) << 4));
+}
+
+// transposed fragment: lane (col = lane&31, h = lane>>5) gets, for j = 0..7,
+// tile[krow0 + 8*(j>>2) + 4h + (j&3)][col0 + col]   -- the k order of an accumulator reused as an operand.
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int krow0, int col0, int lane) {
+  const int h = lane >> 5;
+  const int i16 = lane & 15;
+  const int q = i16 >> 2, p = i16 & 3;
+  const int col = col0 + ((lane >> 4) & 1) * 16 + 4 * p;     // first of this lane's 4 columns
+  const int c = col >> 3, sub = (col & 7) * 2;
+  bf16x8 out;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = krow0 + 8 * u + 4 * h + q;
+    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + r * 128 + ((c ^ swz(r)) << 4) + sub));
+    out[4 * u + 0] = v[0]; out[4 * u + 1] = v[1]; out[4 * u + 2] = v[2]; out[4 * u + 3] = v[3];
+  }
+  return out;
+}
+
+// accumulator (32 keys x 32 queries, fp32) -> two bf16 B-operand fragments (k-steps of 16 keys)
+__device__ __forceinline__ void acc_to_frags(const f32x16& a, bf16x8& f0, bf16x8& f1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { f0[j] = (bf16)a[j]; f1[j] = (bf16)a[8 + j]; }
+}
+
+__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+
+// write a wave's transposed result (acc[b][e]: row = dh 32b + acc_row(e), col = lane&31 = token) to global
+// rows of 64 bf16 through a per-wave LDS patch so that stores are 16 bytes per lane, 128 bytes per row.
+__device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], float mult, char* patch /* 32 x 144 B */, bf16* __restrict__ dst,
+                                                  int64_t ld, int tok0, int ntok, int lane) {
+  const int t = lane & 31;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[b][g4 * 4 + e] * mult);
+      const int dh = 32 * b + 8 * g4 + 4 * (lane >> 5);
+      *reinterpret_cast<bf16x4*>(patch + t * 144 + dh * 2) = v;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 64 + lane;                 // 32 rows x 8 chunks
+    const int r = idx >> 3, c = idx & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(patch + r * 144 + c * 16);
+    if (tok0 + r < ntok) *reinterpret_cast<u32x4*>(dst + (int64_t)(tok0 + r) * ld + c * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+struct FwdArgs {
+  const bf16* qkv; bf16* o; float* lse; const float* key_mask;
+  int S, H; float scale; int causal;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [K0 | V0 | K1 | V1] 32 KiB, then bias[2][64] floats, then 4 per-wave patches of 32x144 B
+  float* bias_s = reinterpret_cast<float*>(smem + 4 * TILE_B);
+  char* patches = smem + 4 * TILE_B + 2 * 64 * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = a.S, H = a.H, D = H * DH;
+  const int64_t ld = 3 * (int64_t)D;
+  const int g = blockIdx.z, h = blockIdx.y;
+  // heaviest (latest) query blocks first under the causal mask
+  const int qb = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+  const int q0 = qb * 128 + wave * 32;             // this wave's first query
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
+  const bf16* Kg = base + D;
+  const bf16* Vg = base + 2 * D;
+  const float* km = a.key_mask ? a.key_mask + (int64_t)g * S : nullptr;
+
+  // Q fragments (B operand): lane (query = lane&31, half) holds Q[q][16ks + 8*half .. +7]
+  bf16x8 qf[4];
+  {
+    int qrow = q0 + (lane & 31);
+    qrow = qrow < S ? qrow : S - 1;
+    const bf16* qp = base + (int64_t)qrow * ld + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+  }
+  const int myq = q0 + (lane & 31);
+
+  int kend = S;                                      // keys needed by this block
+  if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
+  const int nt = (kend + KV_TILE - 1) / KV_TILE;
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[b][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  auto stage = [&](int t, int buf) {
+    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
+    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+    if (tid < 64) {
+      const int key = t * KV_TILE + tid;
+      float b = 0.f;
+      if (key >= S) b = -INFINITY;
+      else if (km) b = (1.0f - km[key]) * -1e9f;
+      bias_s[buf * 64 + tid] = b;
+    }
+  };
+
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const int k0 = t * KV_TILE;
+    const bool active = !a.causal || (k0 <= q0 + 31);      // wave-uniform: tile not entirely above the diagonal
+    if (active && q0 < S) {
+      const char* Kt = smem + buf * 2 * TILE_B;
+      const char* Vt = Kt + TILE_B;
+      // S^T (2 sub-tiles of 32 keys)
+      f32x16 sacc[2];
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[sb][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc[sb], 0, 0, 0);
+      }
+      // scale, mask, running max
+      const bool need_bias = (km != nullptr) || (k0 + KV_TILE > S);
+      const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);   // tile touches the diagonal for some query of this wave
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kl = 32 * sb + acc_row(e, lane);
+          float s = sacc[sb][e] * a.scale;
+          if (need_bias) s += bias_s[buf * 64 + kl];
+          if (diag && (k0 + kl > myq)) s = -INFINITY;
+          sacc[sb][e] = s;
+          tmax = fmaxf(tmax, s);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      // m_new is finite for every real query: key 0 is never above the diagonal and biases are finite for key < S
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = __expf(sacc[sb][e] - m_new);
+          sacc[sb][e] = p;
+          psum += p;
+        }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
+      // O^T += V^T P^T
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        bf16x8 pf[2];
+        acc_to_frags(sacc[sb], pf[0], pf[1]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, 32 * sb + 16 * s2, 32 * b, lane), pf[s2], oacc[b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (q0 >= S) return;
+  const float inv_l = 1.0f / l_run;
+  if (lane < 32 && myq < S) {
+    float* lp = a.lse + (((int64_t)g * H + h) * S + myq) * 2;
+    lp[0] = m_run;
+    lp[1] = __logf(l_run);
+  }
+  // 1/l differs per lane (query): scale per lane, then transpose through the wave's LDS patch
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[b][e] *= inv_l;
+  store_transposed(oacc, 1.0f, patches + wave * (32 * 144), a.o + (int64_t)g * S * D + h * DH, D, q0, S, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward, pass 1: dQ (and delta).  Same geometry as the forward.
+struct BwdArgs {
+  const bf16* qkv; const bf16* o; const bf16* dout; const float* lse; const float* key_mask; bf16* dqkv; float* delta;
+  int S, H; float scale; int causal;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_s = reinterpret_cast<float*>(smem + 4 * TILE_B);
+  char* patches = smem + 4 * TILE_B + 2 * 64 * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = a.S, H = a.H, D = H * DH;
+  const int64_t ld = 3 * (int64_t)D;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int qb = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+  const int q0 = qb * 128 + wave * 32;
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
+  const bf16* Kg = base + D;
+  const bf16* Vg = base + 2 * D;
+  const float* km = a.key_mask ? a.key_mask + (int64_t)g * S : nullptr;
+  const int myq = q0 + (lane & 31);
+  const int qrow = myq < S ? myq : S - 1;
+
+  bf16x8 qf[4], dof[4];
+  float delta = 0.f;
+  {
+    const bf16* qp = base + (int64_t)qrow * ld + 8 * (lane >> 5);
+    const bf16* dop = a.dout + ((int64_t)g * S + qrow) * D + h * DH + 8 * (lane >> 5);
+    const bf16* op = a.o + ((int64_t)g * S + qrow) * D + h * DH + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dop + 16 * ks);
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)ov[j];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+  }
+  float m_q, logl_q;
+  {
+    const float* lp = a.lse + (((int64_t)g * H + h) * S + qrow) * 2;
+    m_q = lp[0];
+    logl_q = lp[1];
+  }
+  if (lane < 32 && myq < S) a.delta[((int64_t)g * H + h) * S + myq] = delta;
+
+  int kend = S;
+  if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
+  const int nt = (kend + KV_TILE - 1) / KV_TILE;
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[b][e] = 0.f;
+
+  auto stage = [&](int t, int buf) {
+    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
+    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+    if (tid < 64) {
+      const int key = t * KV_TILE + tid;
+      float b = 0.f;
+      if (key >= S) b = -INFINITY;
+      else if (km) b = (1.0f - km[key]) * -1e9f;
+      bias_s[buf * 64 + tid] = b;
+    }
+  };
+
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const int k0 = t * KV_TILE;
+    const bool active = !a.causal || (k0 <= q0 + 31);
+    if (active && q0 < S) {
+      const char* Kt = smem + buf * 2 * TILE_B;
+      const char* Vt = Kt + TILE_B;
+      const bool need_bias = (km != nullptr) || (k0 + KV_TILE > S);
+      const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vt, 32 * sb, ks, lane), dof[ks], dpacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kl = 32 * sb + acc_row(e, lane);
+          float s = sacc[e] * a.scale;
+          if (need_bias) s += bias_s[buf * 64 + kl];
+          float p = __expf((s - m_q) - logl_q);
+          if (diag && (k0 + kl > myq)) p = 0.f;
+          sacc[e] = p * (dpacc[e] - delta) * a.scale;          // dS^T
+        }
+        bf16x8 dsf[2];
+        acc_to_frags(sacc, dsf[0], dsf[1]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            dqacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, 32 * sb + 16 * s2, 32 * b, lane), dsf[s2], dqacc[b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (q0 >= S) return;
+  store_transposed(dqacc, 1.0f, patches + wave * (32 * 144), a.dqkv + (int64_t)g * S * ld + h * DH, ld, q0, S, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV.  workgroup = 4 waves x 32 keys; Q / dO tiles of 64 queries stream through LDS.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [Q0 | dO0 | Q1 | dO1] 32 KiB, stats[2][3][64] floats, 4 patches
+  float* stats = reinterpret_cast<float*>(smem + 4 * TILE_B);
+  char* patches = smem + 4 * TILE_B + 2 * 3 * 64 * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = a.S, H = a.H, D = H * DH;
+  const int64_t ld = 3 * (int64_t)D;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int kb0 = blockIdx.x * 128;                  // block's first key
+  const int key0 = kb0 + wave * 32;                  // wave's first key
+  const int mykey = key0 + (lane & 31);
+  const int krow = mykey < S ? mykey : S - 1;
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
+  const bf16* dO = a.dout + (int64_t)g * S * D + h * DH;
+  const float* lse = a.lse + ((int64_t)g * H + h) * S * 2;
+  const float* dl = a.delta + ((int64_t)g * H + h) * S;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16* kp = base + (int64_t)krow * ld + D + 8 * (lane >> 5);
+    const bf16* vp = base + (int64_t)krow * ld + 2 * D + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
+    }
+  }
+  float bkey = 0.f;
+  if (a.key_mask) bkey = (1.0f - a.key_mask[(int64_t)g * S + krow]) * -1e9f;
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dkacc[b][e] = 0.f; dvacc[b][e] = 0.f; }
+
+  const int t0 = a.causal ? kb0 / 64 : 0;            // first query tile that can see this block's keys
+  const int nt = (S + 63) / 64;
+
+  auto stage = [&](int t, int buf) {
+    stage64(base, ld, t * 64, S, smem + buf * 2 * TILE_B, wave, lane);
+    stage64(dO, D, t * 64, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+    if (tid < 64) {
+      int q = t * 64 + tid;
+      q = q < S ? q : S - 1;
+      float* st = stats + buf * 192;
+      st[tid] = lse[q * 2];
+      st[64 + tid] = lse[q * 2 + 1];
+      st[128 + tid] = dl[q];
+    }
+  };
+
+  if (t0 < nt) {
+    stage(t0, 0);
+    __syncthreads();
+  }
+  for (int t = t0; t < nt; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const int qt0 = t * 64;
+    const bool active = (key0 < S) && (!a.causal || (qt0 + 63 >= key0));
+    if (active) {
+      const char* Qt = smem + buf * 2 * TILE_B;
+      const char* dOt = Qt + TILE_B;
+      const float* st = stats + buf * 192;
+#pragma unroll
+      for (int sq = 0; sq < 2; ++sq) {
+        const int qs0 = qt0 + 32 * sq;
+        if (a.causal && qs0 + 31 < key0) continue;   // wave-uniform
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qt, 32 * sq, ks, lane), kf[ks], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dOt, 32 * sq, ks, lane), vf[ks], dpacc, 0, 0, 0);
+        }
+        const bool diag = a.causal && (qs0 < key0 + 31);
+        const bool tail = qs0 + 32 > S;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ql = 32 * sq + 8 * g4 + 4 * (lane >> 5);          // 4 consecutive local query rows
+          const f32x4 mv = *reinterpret_cast<const f32x4*>(st + ql);
+          const f32x4 lv = *reinterpret_cast<const f32x4*>(st + 64 + ql);
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(st + 128 + ql);
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int e = g4 * 4 + e4;
+            const int q = qt0 + ql + e4;
+            const float s = sacc[e] * a.scale + bkey;
+            float p = __expf((s - mv[e4]) - lv[e4]);
+            if ((diag && mykey > q) || (tail && q >= S)) p = 0.f;
+            sacc[e] = p;
+            dpacc[e] = p * (dpacc[e] - dv[e4]) * a.scale;
+          }
+        }
+        bf16x8 pf[2], dsf[2];
+        acc_to_frags(sacc, pf[0], pf[1]);
+        acc_to_frags(dpacc, dsf[0], dsf[1]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            dvacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOt, 32 * sq + 16 * s2, 32 * b, lane), pf[s2], dvacc[b], 0, 0, 0);
+            dkacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 32 * sq + 16 * s2, 32 * b, lane), dsf[s2], dkacc[b], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (key0 >= S) return;
+  char* patch = patches + wave * (32 * 144);
+  store_transposed(dkacc, 1.0f, patch, a.dqkv + (int64_t)g * S * ld + D + h * DH, ld, key0, S, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  store_transposed(dvacc, 1.0f, patch, a.dqkv + (int64_t)g * S * ld + 2 * D + h * DH, ld, key0, S, lane);
+}
+
+constexpr int BWD_DKV_LDS = 4 * TILE_B + 2 * 3 * 64 * 4 + 4 * 32 * 144;
+constexpr int FWD_LDS = 4 * TILE_B + 2 * 64 * 4 + 4 * 32 * 144;
+
+}  // namespace
+
+// Head dims other than 64 (e.g. the reference's default 8 heads -> Dh = 96) take a widening detour:
+// bf16 -> f32 copies in the workspace, the fp32 attention core, f32 -> bf16.  Correct for any Dh, not fast.
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh) {
+  if (Dh == DH) return (size_t)G * H * S * sizeof(float);       // delta = rowsum(dO * O)
+  const size_t T = (size_t)G * S, D = (size_t)H * Dh;
+  return 2 * align256(T * 3 * D * 4) + 2 * align256(T * D * 4) + attn_f32_ws(G, S, H, Dh);
+}
+
+static int cast_async(const void* src, int sd, void* dst, int dd, int64_t n, hipStream_t st) { return meant_cast(src, sd, dst, dd, n, st); }
+
+static int attn_bf16_generic(bool backward, const bf16* qkv, const bf16* o, const bf16* dout, bf16* o_out, float* lse, const float* key_mask,
+                             bf16* dqkv, int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes,
+                             hipStream_t stream) {
+  MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn(bf16, Dh=%d): workspace too small", Dh);
+  const int64_t T = G * S, D = (int64_t)H * Dh;
+  char* w = (char*)ws;
+  float* qkv32 = (float*)w; w += align256((size_t)T * 3 * D * 4);
+  float* dqkv32 = (float*)w; w += align256((size_t)T * 3 * D * 4);
+  float* o32 = (float*)w; w += align256((size_t)T * D * 4);
+  float* do32 = (float*)w; w += align256((size_t)T * D * 4);
+  const size_t rest = ws_bytes - (size_t)(w - (char*)ws);
+  int rc;
+  if ((rc = cast_async(qkv, MEANT_BF16, qkv32, MEANT_F32, T * 3 * D, stream))) return rc;
+  if (!backward) {
+    if ((rc = attn_f32_fwd(qkv32, o32, lse, key_mask, G, S, H, Dh, scale, causal, w, rest, stream))) return rc;
+    return cast_async(o32, MEANT_F32, o_out, MEANT_BF16, T * D, stream);
+  }
+  if ((rc = cast_async(dout, MEANT_BF16, do32, MEANT_F32, T * D, stream))) return rc;
+  if ((rc = attn_f32_bwd(qkv32, o32, do32, lse, key_mask, dqkv32, G, S, H, Dh, scale, causal, w, rest, stream))) return rc;
+  (void)o;
+  return cast_async(dqkv32, MEANT_F32, dqkv, MEANT_BF16, T * 3 * D, stream);
+}
+
+static int attn_bf16_check(const char* name, int64_t G, int64_t S, int H, int Dh) {
+  (void)Dh;
+  MEANT_REQUIRE(G <= 65535 && H <= 65535 && S < (1 << 24), MEANT_ERR_UNSUPPORTED, "%s: G=%lld / H=%d / S=%lld exceed the grid limits",
+                name, (long long)G, H, (long long)S);
+  return MEANT_OK;
+}
+
+int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh, float scale,
+                  int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (Dh != DH) return attn_bf16_generic(false, qkv, nullptr, nullptr, o, lse, key_mask, nullptr, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
+  int rc = attn_bf16_check("attn_fwd", G, S, H, Dh);
+  if (rc) return rc;
+  MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o), MEANT_ERR_ARG, "attn_fwd: 16-byte alignment");
+  FwdArgs a{qkv, o, lse, key_mask, (int)S, H, scale, causal};
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS); attr_set = true; }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
+  MEANT_LAUNCH_CHECK("attn_fwd");
+  return MEANT_OK;
+}
+
+int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv, int64_t G,
+                  int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (Dh != DH) return attn_bf16_generic(true, qkv, o, dout, nullptr, const_cast<float*>(lse), key_mask, dqkv, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
+  int rc = attn_bf16_check("attn_bwd", G, S, H, Dh);
+  if (rc) return rc;
+  MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn_bwd: workspace too small");
+  MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o) && meant_aligned16(dout) && meant_aligned16(dqkv), MEANT_ERR_ARG,
+                "attn_bwd: 16-byte alignment");
+  BwdArgs a{qkv, o, dout, lse, key_mask, dqkv, (float*)ws, (int)S, H, scale, causal};
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DKV_LDS);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), FWD_LDS, stream, a);
+  MEANT_LAUNCH_CHECK("attn_bwd_dq");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), BWD_DKV_LDS, stream, a);
+  MEANT_LAUNCH_CHECK("attn_bwd_dkv");
+  return MEANT_OK;
+}

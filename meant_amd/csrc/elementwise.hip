@@ -153,8 +153,8 @@ __global__ __launch_bounds__(EW_THREADS) void patchify_kernel(const TI* __restri
 
 // ------------------------------------------------------------------------------------------------
 // K8 mean over the sequence axis.  block = (g, 256-column slab): 32 chunks x 8 row groups.
-template <typename T>
-__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t ld_out,
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__ x, TO* __restrict__ out, int64_t ld_out,
                                                             int64_t col_off, int S, int d) {
   __shared__ float red[8][32][9];
   const int64_t g = blockIdx.x;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__
   for (int k = 0; k < 8; ++k) red[rg][threadIdx.x & 31][k] = acc[k];
   __syncthreads();
   if (rg == 0 && chunk * 8 < d) {
-    Vec8<T> o;
+    Vec8<TO> o;
     const float inv = 1.0f / (float)S;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__
       for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x][k];
       o.set(k, s * inv);
     }
-    store8<T>(out + g * ld_out + col_off + chunk * 8, o);
+    store8<TO>(out + g * ld_out + col_off + chunk * 8, o);
   }
 }
-template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void meanpool_bwd_kernel(const T* __restrict__ dout, int64_t ld_out, int64_t col_off,
+template <typename T, typename TO>
+__global__ __launch_bounds__(EW_THREADS) void meanpool_bwd_kernel(const TO* __restrict__ dout, int64_t ld_out, int64_t col_off,
                                                                    T* __restrict__ dx, int64_t G, int S, int d) {
   const int nch = d >> 3;
   const int64_t total = G * S * (int64_t)nch;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(EW_THREADS) void meanpool_bwd_kernel(const T* __res
     const int ch = (int)(i % nch);
     const int64_t gs = i / nch;
     const int64_t g = gs / S;
-    const Vec8<T> v = load8<T>(dout + g * ld_out + col_off + ch * 8);
+    const Vec8<TO> v = load8<TO>(dout + g * ld_out + col_off + ch * 8);
     Vec8<T> o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o.set(k, v.get(k) * inv);
@@ -416,20 +416,26 @@ extern "C" int meant_patchify(const void* images, int images_dtype, void* patche
   return MEANT_OK;
 }
 
-extern "C" int meant_meanpool_fwd(const void* x, void* out, int64_t ld_out, int64_t col_off, int64_t G, int64_t S, int64_t d, int dtype, void* stream) {
+extern "C" int meant_meanpool_fwd(const void* x, void* out, int64_t ld_out, int64_t col_off, int64_t G, int64_t S, int64_t d, int dtype, int out_dtype, void* stream) {
   EW_REQ(x && out && G > 0 && S > 0 && d > 0 && d % 8 == 0 && ld_out % 8 == 0 && col_off % 8 == 0 && col_off + d <= ld_out, "meanpool_fwd: bad argument");
   EW_REQ(G < 2147483647LL, "meanpool_fwd: too many groups");
-  DISPATCH_DTYPE(dtype, T,
-                 hipLaunchKernelGGL(meanpool_fwd_kernel<T>, dim3((unsigned)G, (unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
-                                    (const T*)x, (T*)out, ld_out, col_off, (int)S, (int)d));
+  const dim3 grid((unsigned)G, (unsigned)ceil_div(d, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEANT_F32 && out_dtype == MEANT_F32) hipLaunchKernelGGL((meanpool_fwd_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)out, ld_out, col_off, (int)S, (int)d);
+  else if (dtype == MEANT_BF16 && out_dtype == MEANT_F32) hipLaunchKernelGGL((meanpool_fwd_kernel<bf16, float>), grid, block, 0, st, (const bf16*)x, (float*)out, ld_out, col_off, (int)S, (int)d);
+  else if (dtype == MEANT_BF16 && out_dtype == MEANT_BF16) hipLaunchKernelGGL((meanpool_fwd_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)x, (bf16*)out, ld_out, col_off, (int)S, (int)d);
+  else { meant_set_error("meanpool_fwd: unsupported dtype combination"); return MEANT_ERR_UNSUPPORTED; }
   MEANT_LAUNCH_CHECK("meanpool_fwd");
   return MEANT_OK;
 }
-extern "C" int meant_meanpool_bwd(const void* dout, int64_t ld_out, int64_t col_off, void* dx, int64_t G, int64_t S, int64_t d, int dtype, void* stream) {
+extern "C" int meant_meanpool_bwd(const void* dout, int64_t ld_out, int64_t col_off, void* dx, int64_t G, int64_t S, int64_t d, int dtype, int out_dtype, void* stream) {
   EW_REQ(dout && dx && G > 0 && S > 0 && d > 0 && d % 8 == 0 && ld_out % 8 == 0 && col_off % 8 == 0, "meanpool_bwd: bad argument");
-  DISPATCH_DTYPE(dtype, T,
-                 hipLaunchKernelGGL(meanpool_bwd_kernel<T>, dim3(ew_blocks(G * S * (d / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                                    (const T*)dout, ld_out, col_off, (T*)dx, G, (int)S, (int)d));
+  const dim3 grid(ew_blocks(G * S * (d / 8))), block(EW_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEANT_F32 && out_dtype == MEANT_F32) hipLaunchKernelGGL((meanpool_bwd_kernel<float, float>), grid, block, 0, st, (const float*)dout, ld_out, col_off, (float*)dx, G, (int)S, (int)d);
+  else if (dtype == MEANT_BF16 && out_dtype == MEANT_F32) hipLaunchKernelGGL((meanpool_bwd_kernel<bf16, float>), grid, block, 0, st, (const float*)dout, ld_out, col_off, (bf16*)dx, G, (int)S, (int)d);
+  else if (dtype == MEANT_BF16 && out_dtype == MEANT_BF16) hipLaunchKernelGGL((meanpool_bwd_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)dout, ld_out, col_off, (bf16*)dx, G, (int)S, (int)d);
+  else { meant_set_error("meanpool_bwd: unsupported dtype combination"); return MEANT_ERR_UNSUPPORTED; }
   MEANT_LAUNCH_CHECK("meanpool_bwd");
   return MEANT_OK;
 }

@@ -1,0 +1,334 @@
+// K5/K2: bf16 MFMA GEMMs of the MEANT path (the d x d Linears are 84 % of the step's FLOPs).
+//
+//   gemm_bf16_nt : C[M,N] = A[M,K] B[N,K]^T (+bias, GELU / sigmoid, +residual), both operands K-contiguous.
+//                  Serves x W^T (forward) and dY (W^T)^T (input gradient, with a pre-transposed weight).
+//   gemm_bf16_tn : dW[N,K] += dY[M,N]^T X[M,K] (reduction over the token axis M), fp32 atomics into dW.
+//
+// MI355X mapping
+//   * 256 threads = 4 waves (2 x 2), block tile 128 x 128, K-step 64; each wave owns 64 x 64 of C in
+//     16 (NT: 16x16x32) or 4 (TN: 32x32x16) MFMA accumulator tiles (64 accumulator VGPRs).
+//   * operands go HBM -> LDS directly (global_load_lds, 16 B per lane, 1 KiB per wave-instruction),
+//     double-buffered: the DMA of K-tile t+1 is in flight while tile t feeds the MFMAs; one barrier
+//     per K-tile.
+//   * LDS images are lane-linear (a DMA constraint), so the bank-conflict swizzle is applied on the
+//     SOURCE address and again on the read:
+//        NT: 128-byte rows, 16-byte chunk c of row r lives at slot c ^ ((r>>1)&7)   -> ds_read_b128
+//            of an MFMA fragment (16 rows x one chunk per 16-lane group) touches 16 distinct slots.
+//        TN: 256-byte rows (the reduction index is the ROW), chunk c of row r at slot c ^ (4*(r&3));
+//            fragments come out of ds_read_b64_tr_b16 (hardware transpose), 4 consecutive rows each.
+//   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs have private L2s and blocks are dealt
+//     round-robin, so ids are remapped to give each XCD a contiguous run of tiles; consecutive tiles
+//     share the A row-panel (N/128 tiles per panel) which is then served from that XCD's L2, and the
+//     weight matrix (<= 7 MB) stays resident in every L2.
+//   * epilogue: accumulators -> LDS (fp32) -> coalesced 16-byte bf16 stores with bias / activation /
+//     residual applied in fp32 and a single rounding.
+// Roofline: MFMA-bound (dense bf16 peak 2.5 PFLOP/s); algorithmic FLOPs 2*M*N*K per launch.
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
+constexpr int NT_LDS = 4 * TILE_BYTES;           // A0 B0 A1 B1 = 64 KiB (also holds the 128x128 fp32 epilogue tile)
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+// bijective XCD-aware remap of a linear block id (guide: cdna_hip_programming.md T1)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel
+// stage one 128 x 64 bf16 tile (rows row0.., columns k0..k0+63 of a K-contiguous matrix) into LDS.
+// wave w issues DMA pieces 4w..4w+3; piece i covers tile rows 8i..8i+7 (8 lanes per 128-byte row).
+__device__ __forceinline__ void nt_stage(const bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                          char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int slot = lane & 7;
+    const int c = slot ^ ((r >> 1) & 7);
+    int64_t gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;            // clamp: rows past the edge are computed and discarded
+    glds16(g + gr * ld + k0 + c * 8, lds_tile + piece * 1024);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Args a, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = id / ntn, tn = id - tm * ntn;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int nk = (int)(a.K / BK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  nt_stage(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  nt_stage(a.B, a.ldb, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
+  __syncthreads();                                  // (drains the DMA: vmcnt(0) + barrier)
+
+  const int frow = lane & 15, fkg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+    if (kt + 1 < nk) {
+      nt_stage(a.A, a.lda, m0, a.M, (int64_t)(kt + 1) * BK, nxt, wave, lane);
+      nt_stage(a.B, a.ldb, n0, a.N, (int64_t)(kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+    }
+    const char* At = cur + (wm * 64) * 128;
+    const char* Bt = cur + TILE_BYTES + (wn * 64) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int c = ks * 4 + fkg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = i * 16 + frow;
+        const int off = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+        af[i] = *reinterpret_cast<const bf16x8*>(At + off);
+        bfr[i] = *reinterpret_cast<const bf16x8*>(Bt + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc -> LDS fp32 [128][132] -> coalesced stores --------------------------------
+  constexpr int LDC = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem);       // 128*132*4 = 67584 B <= NT_LDS + slack (see launch)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        Cs[(wm * 64 + i * 16 + fkg * 4 + e) * LDC + wn * 64 + j * 16 + frow] = acc[i][j][e];
+  __syncthreads();
+  // thread -> (row = pass*16 + tid/16, 8 columns at (tid%16)*8)
+  const int cc = (tid & 15) * 8;
+  const int64_t n = n0 + cc;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = (a.bias && n + e < a.N) ? a.bias[n + e] : 0.f;
+  const bool vec_ok = (n + 8 <= a.N) && ((a.ldc & 7) == 0) && (!a.residual || (a.ldr & 7) == 0);
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int r = pass * 16 + (tid >> 4);
+    const int64_t m = m0 + r;
+    if (m >= a.M || n >= a.N) continue;
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
+    if (vec_ok) {
+      if (a.preact) {
+        bf16x8 p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = p;
+      }
+      if (a.epilogue & MEANT_EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (a.epilogue & MEANT_EPI_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+      }
+      if (a.residual) {
+        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+      *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
+    } else {
+      for (int e = 0; e < 8 && n + e < a.N; ++e) {
+        float x = v[e];
+        if (a.preact) a.preact[m * a.ldc + n + e] = (bf16)x;
+        if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf(x);
+        if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
+        if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
+        a.C[m * a.ldc + n + e] = (bf16)x;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel: dW[n][k] += sum_m dY[m][n] X[m][k].  LDS tiles are [64 m][128 cols] (256-byte rows).
+constexpr int TN_BKM = 64;
+constexpr int TN_TILE_BYTES = TN_BKM * 128 * 2;    // 16 KiB
+
+// piece i (1 KiB) covers tile rows 4i..4i+3 (16 lanes per 256-byte row); wave w issues pieces 4w..4w+3.
+__device__ __forceinline__ void tn_stage(const bf16* __restrict__ g, int64_t ld, int64_t m0, int64_t mend, int64_t col0,
+                                          int64_t ncols, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int r = piece * 4 + (lane >> 4);
+    const int slot = lane & 15;
+    const int c = slot ^ ((r & 3) << 2);
+    const int64_t gm = m0 + r;
+    int64_t gc = col0 + c * 8;
+    gc = gc + 8 <= ncols ? gc : (ncols >= 8 ? ncols - 8 : 0);     // column clamp (those outputs are discarded)
+    if (gm < mend) {
+      glds16(g + gm * ld + gc, lds_tile + piece * 1024);
+    } else {
+      // rows past the end of the token axis must contribute zero: write the slot this lane would have DMA'd
+      *reinterpret_cast<u32x4*>(lds_tile + piece * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
+// fragment for mfma_32x32x16: lane (col = lane&31, h = lane>>5) needs rows 16*ks + 8h + j (j = 0..7) of column
+// col0 + col: two transposed reads of 4 consecutive rows each.
+__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int ks, int col0, int lane) {
+  const int h = lane >> 5;
+  const int i16 = lane & 15;                       // lane within its 16-lane group
+  const int q = i16 >> 2, p = i16 & 3;
+  const int colblk = col0 + ((lane >> 4) & 1) * 16; // groups 0/1 (and 2/3) take adjacent 16-column blocks
+  const int cbyte = (colblk + 4 * p) * 2;          // byte offset of this lane's 4 columns inside the row
+  const int c16 = cbyte >> 4, sub = cbyte & 15;
+  bf16x8 out;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = 16 * ks + 8 * h + 4 * t + q;
+    const int off = r * 256 + ((c16 ^ ((r & 3) << 2)) << 4) + sub;
+    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + off));
+    out[4 * t + 0] = v[0]; out[4 * t + 1] = v[1]; out[4 * t + 2] = v[2]; out[4 * t + 3] = v[3];
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
+                                                               int64_t ldx, float* __restrict__ dW, int64_t M, int64_t N,
+                                                               int64_t K, int ntn, int ntk, int64_t rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // a split's tiles run on one XCD and share its L2
+  const int tile = bid % (ntn * ntk);
+  const int split = bid / (ntn * ntk);
+  const int tn = tile / ntk, tk = tile - tn * ntk;
+  const int64_t n0 = (int64_t)tn * 128, k0 = (int64_t)tk * 128;
+  const int64_t mbeg = (int64_t)split * rows_per_split;
+  const int64_t mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  if (mbeg >= mend) return;
+  const int nt = (int)((mend - mbeg + TN_BKM - 1) / TN_BKM);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  tn_stage(dY, lddy, mbeg, mend, n0, N, smem, wave, lane);
+  tn_stage(X, ldx, mbeg, mend, k0, K, smem + TN_TILE_BYTES, wave, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * 2 * TN_TILE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TN_TILE_BYTES;
+    if (t + 1 < nt) {
+      tn_stage(dY, lddy, mbeg + (int64_t)(t + 1) * TN_BKM, mend, n0, N, nxt, wave, lane);
+      tn_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, K, nxt + TN_TILE_BYTES, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = tn_frag(cur, ks, wn * 64 + i * 32, lane);
+        bfr[i] = tn_frag(cur + TN_TILE_BYTES, ks, wk * 64 + i * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C layout of 32x32: col = lane&31 (k index), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (n index): every
+  // wave-instruction adds two 128-byte row segments -> the full-rate shape for global float atomics.
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t kcol = k0 + wk * 64 + j * 32 + (lane & 31);
+      if (kcol >= K) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t nrow = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (nrow < N) atomicAdd(dW + nrow * K + kcol, acc[i][j][e]);
+      }
+    }
+}
+
+}  // namespace
+
+int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
+  MEANT_REQUIRE(a.A && a.B && a.C, MEANT_ERR_ARG, "gemm_bf16_nt: null pointer");
+  MEANT_REQUIRE(a.K % BK == 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: K=%lld must be a multiple of %d (use the fp32 tier otherwise)", (long long)a.K, BK);
+  MEANT_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0 && meant_aligned16(a.A) && meant_aligned16(a.B), MEANT_ERR_ARG,
+                "gemm_bf16_nt: operands must be 16-byte aligned with row strides that are multiples of 8");
+  const int64_t ntm = ceil_div(a.M, BM), ntn = ceil_div(a.N, BN);
+  MEANT_REQUIRE(ntm * ntn < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
+  const size_t lds = 128 * (128 + 4) * sizeof(float);   // 67584 B: covers the 64 KiB of staging buffers too
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntm * ntn)), dim3(256), lds, stream, a, (int)ntm, (int)ntn);
+  MEANT_LAUNCH_CHECK("gemm_bf16_nt");
+  return MEANT_OK;
+}
+
+int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N,
+                        int64_t K, hipStream_t stream) {
+  MEANT_REQUIRE((lddy % 8) == 0 && (ldx % 8) == 0 && meant_aligned16(dY) && meant_aligned16(X), MEANT_ERR_ARG,
+                "gemm_bf16_tn: operands must be 16-byte aligned with row strides that are multiples of 8");
+  MEANT_REQUIRE(N >= 8 && K >= 8, MEANT_ERR_UNSUPPORTED, "gemm_bf16_tn: N and K must be >= 8");
+  const int64_t ntn = ceil_div(N, 128), ntk = ceil_div(K, 128);
+  // split the token axis so that the launch has >= ~4 blocks per CU; each split is a multiple of 64 rows
+  int64_t splits = ceil_div(1024, ntn * ntk);
+  const int64_t max_splits = ceil_div(M, 256);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int64_t rows_per = ceil_div(ceil_div(M, splits), TN_BKM) * TN_BKM;
+  splits = ceil_div(M, rows_per);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN_TILE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((unsigned)(ntn * ntk * splits)), dim3(256), 4 * TN_TILE_BYTES, stream, dY, lddy, X,
+                     ldx, dW, M, N, K, (int)ntn, (int)ntk, rows_per);
+  MEANT_LAUNCH_CHECK("gemm_bf16_tn");
+  if (dbias) return colsum_launch(dY, lddy, dbias, M, N, MEANT_BF16, 1, stream);
+  return MEANT_OK;
+}

@@ -15,6 +15,7 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = 68;
 
+template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
   __shared__ float As[BK][LDS_LD];
   __shared__ float Bs[BK][LDS_LD];
@@ -23,8 +24,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
   const int64_t b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
-  const float* A = a.A + b1 * a.sA[0] + b2 * a.sA[1];
-  const float* B = a.B + b1 * a.sB[0] + b2 * a.sB[1];
+  const TI* A = (const TI*)a.A + b1 * a.sA[0] + b2 * a.sA[1];
+  const TI* B = (const TI*)a.B + b1 * a.sB[0] + b2 * a.sB[1];
+  TO* Cp = (TO*)a.C;
+  const TO* Rp = (const TO*)a.residual;
+  TO* Pp = (TO*)a.preact;
   const int64_t coff = b1 * a.sC[0] + b2 * a.sC[1];
 
   // thread -> (row, k) assignment follows the contiguous axis of each operand
@@ -42,9 +46,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + am[i], k = k0 + ak[i];
-      ra[i] = (m < a.M && k < a.K) ? A[m * a.sA[2] + k * a.sA[3]] : 0.f;
+      ra[i] = (m < a.M && k < a.K) ? to_f(A[m * a.sA[2] + k * a.sA[3]]) : 0.f;
       const int64_t n = n0 + bn[i], kb = k0 + bk[i];
-      rb[i] = (n < a.N && kb < a.K) ? B[kb * a.sB[2] + n * a.sB[3]] : 0.f;
+      rb[i] = (n < a.N && kb < a.K) ? to_f(B[kb * a.sB[2] + n * a.sB[3]]) : 0.f;
     }
   };
 
@@ -74,12 +78,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
     if (m >= a.M) continue;
     const int64_t off = coff + m * a.sC[2] + n * a.sC[3];
     float v = acc[r] * a.alpha + bias;
-    if (a.preact) a.preact[off] = v;
+    if (Pp) Pp[off] = from_f<TO>(v);
     if (a.epilogue & MEANT_EPI_GELU) v = gelu_erf(v);
     if (a.epilogue & MEANT_EPI_SIGMOID) v = 1.f / (1.f + __expf(-v));
-    if (a.residual) v += a.residual[off];
-    if (a.accumulate) v += a.C[off];
-    a.C[off] = v;
+    if (Rp) v += to_f(Rp[off]);
+    if (a.accumulate) v += to_f(Cp[off]);
+    Cp[off] = from_f<TO>(v);
   }
 }
 
@@ -110,19 +114,25 @@ int gemm_f32_launch(const GemmF32Args& a, hipStream_t stream) {
   MEANT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.nb1 > 0 && a.nb2 > 0, MEANT_ERR_ARG, "gemm_f32: bad shape");
   const int64_t gy = ceil_div(a.M, BM), gz = a.nb1 * a.nb2;
   MEANT_REQUIRE(gy <= 65535 * 1024LL && gz <= 65535, MEANT_ERR_UNSUPPORTED, "gemm_f32: grid too large");
+  void (*kern)(GemmF32Args) = nullptr;
+  if (a.in_dtype == MEANT_F32 && a.out_dtype == MEANT_F32) kern = gemm_f32_kernel<float, float>;
+  else if (a.in_dtype == MEANT_BF16 && a.out_dtype == MEANT_BF16) kern = gemm_f32_kernel<bf16, bf16>;
+  else if (a.in_dtype == MEANT_BF16 && a.out_dtype == MEANT_F32) kern = gemm_f32_kernel<bf16, float>;
+  MEANT_REQUIRE(kern, MEANT_ERR_UNSUPPORTED, "gemm_f32: unsupported dtype combination");
+  const size_t esz_in = a.in_dtype == MEANT_F32 ? 4 : 2, esz_out = a.out_dtype == MEANT_F32 ? 4 : 2;
   if (gy <= 65535) {
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)ceil_div(a.N, BN), (unsigned)gy, (unsigned)gz), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.N, BN), (unsigned)gy, (unsigned)gz), dim3(256), 0, stream, a);
   } else {
     // split very tall problems into row slabs so gridDim.y stays legal
     const int64_t slab = 65535LL * BM;
     for (int64_t m = 0; m < a.M; m += slab) {
       GemmF32Args s = a;
-      s.A = a.A + m * a.sA[2];
-      s.C = a.C + m * a.sC[2];
-      if (a.residual) s.residual = a.residual + m * a.sC[2];
-      if (a.preact) s.preact = a.preact + m * a.sC[2];
+      s.A = (const char*)a.A + m * a.sA[2] * esz_in;
+      s.C = (char*)a.C + m * a.sC[2] * esz_out;
+      if (a.residual) s.residual = (const char*)a.residual + m * a.sC[2] * esz_out;
+      if (a.preact) s.preact = (char*)a.preact + m * a.sC[2] * esz_out;
       s.M = (a.M - m < slab) ? a.M - m : slab;
-      hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)ceil_div(a.N, BN), (unsigned)ceil_div(s.M, BM), (unsigned)gz), dim3(256), 0, stream, s);
+      hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.N, BN), (unsigned)ceil_div(s.M, BM), (unsigned)gz), dim3(256), 0, stream, s);
     }
   }
   MEANT_LAUNCH_CHECK("gemm_f32");

@@ -5,7 +5,9 @@
 // Generic strided batched fp32 GEMM on the f32 MFMA (exact fp32 products, v_mfma_f32_32x32x2_f32):
 //   C(b1,b2)[m,n] = act(alpha * sum_k A(m,k) B(k,n) + bias[n]) (+ residual(m,n)) (+ C if accumulate)
 struct GemmF32Args {
-  const float* A; const float* B; float* C;
+  const void* A; const void* B; void* C;
+  int in_dtype = MEANT_F32;   // storage of A and B (bf16 operands are widened to f32 in LDS: slow, exact, any shape)
+  int out_dtype = MEANT_F32;  // storage of C, residual, preact
   int64_t M, N, K, nb1, nb2;
   int64_t sA[4];  // b1, b2, m, k
   int64_t sB[4];  // b1, b2, k, n
@@ -13,8 +15,8 @@ struct GemmF32Args {
   float alpha;
   int accumulate;
   const float* bias;        // [N] or null
-  const float* residual;    // same strides as C, or null
-  float* preact;            // same strides as C, or null (value before the activation)
+  const void* residual;     // same strides as C, or null
+  void* preact;             // same strides as C, or null (value before the activation)
   int epilogue;             // meant_epilogue flags
 };
 int gemm_f32_launch(const GemmF32Args& a, hipStream_t stream);
@@ -45,7 +47,7 @@ int attn_f32_bwd(const float* qkv, const float* o, const float* dout, const floa
                  int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t attn_f32_ws(int64_t G, int64_t S, int H, int Dh);
 int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
-                  float scale, int causal, hipStream_t stream);
+                  float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
 int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv,
                   int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh);

@@ -343,7 +343,8 @@ def temporal_attention(x, wq, bq, wk, bk, wv, bv, num_heads):
 
 # ---------------------------------------------------------------------------------------------
 class _MeanPoolCat(torch.autograd.Function):
-    """torch.cat([mean_s(a), mean_n(b)], -1) of meant/meant.py:231 (b optional)."""
+    """torch.cat([mean_s(a), mean_n(b)], -1) of meant/meant.py:231 (b optional).  The pooled features
+    are emitted in fp32 in both tiers: the temporal encoder and the head (0.06 % of the FLOPs) stay fp32."""
 
     @staticmethod
     def forward(ctx, a, b):
@@ -355,24 +356,25 @@ class _MeanPoolCat(torch.autograd.Function):
             b = _c(b)
             assert b.shape[0] == G and b.dtype == a.dtype
             db_ = b.shape[2]
-        out = torch.empty((G, da + db_), device=a.device, dtype=a.dtype)
-        check(lib.meant_meanpool_fwd(_p(a), _p(out), da + db_, 0, G, S, da, _dt(a), _stream()), "meanpool_fwd")
+        out = torch.empty((G, da + db_), device=a.device, dtype=torch.float32)
+        check(lib.meant_meanpool_fwd(_p(a), _p(out), da + db_, 0, G, S, da, _dt(a), F32, _stream()), "meanpool_fwd")
         if b is not None:
-            check(lib.meant_meanpool_fwd(_p(b), _p(out), da + db_, da, G, b.shape[1], db_, _dt(a), _stream()), "meanpool_fwd")
-        ctx.meta = (a.shape, None if b is None else b.shape)
+            check(lib.meant_meanpool_fwd(_p(b), _p(out), da + db_, da, G, b.shape[1], db_, _dt(a), F32, _stream()), "meanpool_fwd")
+        ctx.meta = (a.shape, None if b is None else b.shape, a.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        sa, sb = ctx.meta
-        dout = _c(dout)
+        sa, sb, dtype = ctx.meta
+        dout = _c(dout.float())
         ld = dout.shape[1]
-        da = torch.empty(sa, device=dout.device, dtype=dout.dtype)
-        check(lib.meant_meanpool_bwd(_p(dout), ld, 0, _p(da), sa[0], sa[1], sa[2], _dt(dout), _stream()), "meanpool_bwd")
+        dti = F32 if dtype == torch.float32 else BF16
+        da = torch.empty(sa, device=dout.device, dtype=dtype)
+        check(lib.meant_meanpool_bwd(_p(dout), ld, 0, _p(da), sa[0], sa[1], sa[2], dti, F32, _stream()), "meanpool_bwd")
         db = None
         if sb is not None:
-            db = torch.empty(sb, device=dout.device, dtype=dout.dtype)
-            check(lib.meant_meanpool_bwd(_p(dout), ld, sa[2], _p(db), sb[0], sb[1], sb[2], _dt(dout), _stream()), "meanpool_bwd")
+            db = torch.empty(sb, device=dout.device, dtype=dtype)
+            check(lib.meant_meanpool_bwd(_p(dout), ld, sa[2], _p(db), sb[0], sb[1], sb[2], dti, F32, _stream()), "meanpool_bwd")
         return da, db
 
 

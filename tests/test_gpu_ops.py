@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import DTYPES, IDS, TOL, t, assert_close, assert_grad_close, pair, compare_param_grads
+from tests.util import DTYPES, IDS, TOL, t, assert_close, assert_grad_close, pair, compare_param_grads, norm_floor
 
 pytestmark = pytest.mark.gpu
 
@@ -214,13 +214,15 @@ def test_attention_modules_golden(M, O, dev, golden, dtype, name, kind):
     assert_close(y, t(g["y"]), tol["out"] * (1 if dtype == torch.float32 else 4), "y")
     assert_grad_close(x.grad, t(g["dx"]), tol["gelem"], "dx")
     params = dict(hip.named_parameters())
+    floor = norm_floor(g["grad_norms"], dtype)
     for nm, refn in zip(g["grad_names"], g["grad_norms"]):
         p = params[str(nm)]
         a = p.grad.double().norm().item()
-        assert abs(a - refn) <= tol["gnorm"] * max(refn, 1e-4), (nm, a, refn)
-        ga = t(g["grad__" + str(nm)])
-        got = p.grad if p.grad.numel() <= 4096 else p.grad[:4]
-        assert_grad_close(got, ga, tol["gelem"] * 2, str(nm))
+        assert abs(a - refn) <= tol["gnorm"] * max(refn, floor), (nm, a, refn)
+        if refn > floor:
+            ga = t(g["grad__" + str(nm)])
+            got = p.grad if p.grad.numel() <= 4096 else p.grad[:4]
+            assert_grad_close(got, ga, tol["gelem"] * 2, str(nm))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
@@ -262,9 +264,10 @@ def test_temporal_golden(M, O, dev, golden, dtype):
     assert_close(y, t(g["y"]), tol["out"] * (1 if dtype == torch.float32 else 4), "y")
     assert_grad_close(x.grad, t(g["dx"]), tol["gelem"], "dx")
     params = dict(hip.named_parameters())
+    floor = norm_floor(g["grad_norms"], dtype)
     for nm, refn in zip(g["grad_names"], g["grad_norms"]):
         a = params[str(nm)].grad.double().norm().item()
-        assert abs(a - refn) <= tol["gnorm"] * max(refn, 1e-4), (nm, a, refn)
+        assert abs(a - refn) <= tol["gnorm"] * max(refn, floor), (nm, a, refn)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
@@ -276,11 +279,12 @@ def test_meanpool_patchify_embedding_rowvec(M, O, dev, dtype):
     ah, bh = a.to(dev).to(dtype).requires_grad_(), b.to(dev).to(dtype).requires_grad_()
     out = ops.meanpool_cat(ah, bh)
     ref = torch.cat((a.to(dtype).float().mean(1), b.to(dtype).float().mean(1)), dim=1)
-    assert_close(out, ref, 1e-5 if dtype == torch.float32 else 1e-2, "meanpool")
-    w = torch.randn_like(out.float())
-    out.backward(w.to(dtype))
-    assert_close(ah.grad, (w[:, :128].to(dtype).float().cpu() / 37)[:, None, :].expand(6, 37, 128), 1e-6 if dtype == torch.float32 else 1e-3, "d meanpool a")
-    assert_close(bh.grad, (w[:, 128:].to(dtype).float().cpu() / 196)[:, None, :].expand(6, 196, 256), 1e-6 if dtype == torch.float32 else 1e-3, "d meanpool b")
+    assert out.dtype == torch.float32
+    assert_close(out, ref, 1e-5, "meanpool")
+    w = torch.randn_like(out)
+    out.backward(w)
+    assert_close(ah.grad, (w[:, :128].cpu() / 37)[:, None, :].expand(6, 37, 128), 1e-6 if dtype == torch.float32 else 1e-3, "d meanpool a")
+    assert_close(bh.grad, (w[:, 128:].cpu() / 196)[:, None, :].expand(6, 196, 256), 1e-6 if dtype == torch.float32 else 1e-3, "d meanpool b")
     # patchify (exact data movement)
     img = t(rs.standard_normal((3, 4, 32, 48)).astype("float32"))
     got = ops.patchify(img.to(dev), 16, dtype)

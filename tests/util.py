@@ -40,9 +40,18 @@ def pair(oracle_mod, hip_mod, seed, dev):
     return oracle_mod, hip_mod.to(dev).eval()
 
 
+def norm_floor(ref_norms, dtype):
+    """Gradients that are structurally ~0 in exact arithmetic (e.g. the key bias, to which a softmax is
+    invariant) are pure rounding noise; norms are compared against max(ref, floor), floor being a small
+    fraction of the largest gradient norm of the module."""
+    big = max([float(x) for x in ref_norms] + [1e-12])
+    return (1e-4 if dtype == torch.float32 else 2e-2) * big
+
+
 def compare_param_grads(oracle_mod, hip_mod, dtype, what=""):
     tol = TOL[dtype]
     ref = dict(oracle_mod.named_parameters())
+    floor = norm_floor([r.grad.double().norm().item() for r in ref.values() if r.grad is not None], dtype)
     for k, p in hip_mod.named_parameters():
         r = ref[k]
         if r.grad is None:
@@ -50,5 +59,6 @@ def compare_param_grads(oracle_mod, hip_mod, dtype, what=""):
             continue
         assert p.grad is not None, f"{what}:{k} missing grad"
         a, b = p.grad.detach().double().cpu().norm().item(), r.grad.double().norm().item()
-        assert abs(a - b) <= tol["gnorm"] * max(b, 1e-5) + 1e-7, f"{what}:{k} grad norm {a} vs {b}"
-        assert_grad_close(p.grad, r.grad, tol["gelem"], f"{what}:{k}")
+        assert abs(a - b) <= tol["gnorm"] * max(b, floor) + 1e-7, f"{what}:{k} grad norm {a} vs {b}"
+        if b > floor:
+            assert_grad_close(p.grad, r.grad, tol["gelem"], f"{what}:{k}")
