@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/sec, forward+backward, full MEANT (tweet + image), lag=12, d=768, 12 heads,
+512-token text, 224x224 p=16 patches, E=1 encoder layer, bf16 compute (fp32 master weights, fp32
+statistics/softmax/accumulators), synthetic inputs, random-init weights -- BASELINE.json configs[2]/[3].
+
+    python bench.py --gpus 1 --steps K --warmup W                       # one MI355X
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                            # N ranks, RCCL grad all-reduce
+
+A step = one pass of the hot path over one batch: forward (train mode: the languageEncoder's Dropout(0.5)
+is live, fused into the RMSNorm kernel), cross-entropy on the probabilities (in_loop_train.py:232),
+backward to every parameter gradient (incl. the 64001x768 embedding), and for N>1 the bucketed
+gradient all-reduce overlapped with backward.  No optimizer step (the metric is fwd+bwd).
+Weak scaling: 128 samples per GPU (global batch 1024 at 8 GPUs, BASELINE.json configs[3]).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- the dominant kernel (gemm_bf16_nt_kernel, MFMA-bound): algorithmic FLOPs of its launches
+                  / their HIP-event durations, measured live inside the timed steps;
+  cpu_baseline -- the CPU oracle (a port: the reference is Python and cannot travel) timed on the host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16 peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+V, D, H, L, S, IMG, P, C, NCLS = 64001, 768, 12, 12, 512, 224, 16, 4, 2
+
+
+def flops_per_sample(E: int) -> float:
+    """fwd = 3.88 + 91.26 E GFLOP (full-square attention), fwd+bwd = 3x."""
+    return 3.0 * (3.88 + 91.26 * E) * 1e9
+
+
+class GemmTimer:
+    """HIP-event timing of every launch of the dominant kernel (the bf16 NT GEMM behind Linear forward
+    and input-gradient) during the timed steps.  Events are recorded on the stream the kernel is
+    launched on (torch's current stream, which the C ABI receives)."""
+
+    def __init__(self):
+        self.recs = []
+        self.enabled = False
+
+    def install(self):
+        from meant_amd import ops
+        lib = ops.lib
+        timer = self
+
+        def wrap(name, flops_of):
+            orig = getattr(lib, name)
+
+            def call(*a):
+                if not timer.enabled:
+                    return orig(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(*a)
+                e1.record()
+                timer.recs.append((e0, e1, flops_of(a)))
+                return rc
+            return call
+
+        class LibProxy:
+            def __getattr__(self_, n):
+                return getattr(lib, n)
+        proxy = LibProxy()
+        # meant_linear_fwd(x, ldx, w, bias, res, ldr, y, ldy, pre, M, N, K, epi, dtype, stream)
+        proxy.meant_linear_fwd = wrap("meant_linear_fwd", lambda a: 2.0 * a[9] * a[10] * a[11] if a[13] == 1 and a[11] % 64 == 0 else 0.0)
+        # meant_linear_bwd_dx(dy, lddy, wT, dx, lddx, M, N, K, dtype, stream)
+        proxy.meant_linear_bwd_dx = wrap("meant_linear_bwd_dx", lambda a: 2.0 * a[5] * a[6] * a[7] if a[8] == 1 and a[6] % 64 == 0 else 0.0)
+        ops.lib = proxy
+
+    def summary(self):
+        tot_t, tot_f, n = 0.0, 0.0, 0
+        for e0, e1, f in self.recs:
+            if f <= 0:
+                continue
+            tot_t += e0.elapsed_time(e1) * 1e-3
+            tot_f += f
+            n += 1
+        return n, tot_f, tot_t
+
+
+def build_model(E: int, device):
+    import meant_amd
+    torch.manual_seed(1234)
+    emb = torch.nn.Embedding(V, D)
+    m = meant_amd.meant(D, D, 4, IMG, IMG, P, L, NCLS, emb, num_heads=H, num_encoders=E, channels=C)
+    m.compute_dtype = torch.bfloat16
+    return m.to(device)
+
+
+def make_batch(B: int, rank: int, device):
+    rs = np.random.RandomState(99 + rank)
+    tweets = torch.from_numpy(rs.randint(0, V, (B, L, S)).astype("int64")).to(device)
+    images = torch.randn(B, L, C, IMG, IMG, device=device, generator=torch.Generator(device=device).manual_seed(99 + rank))
+    mask = torch.ones(B, L, S)
+    pad = rs.randint(0, 384, (B, L))
+    for b in range(B):
+        for l in range(L):
+            if pad[b, l]:
+                mask[b, l, S - pad[b, l]:] = 0
+    target = torch.from_numpy(rs.randint(0, NCLS, (B,)).astype("int64")).to(device)
+    return tweets, images, mask.to(device), target
+
+
+def cpu_baseline(E: int, seconds_budget: float = 25.0):
+    """the oracle on the host cores: C3 config, B=1, fp32 eager, eval mode, fwd + CE + bwd"""
+    from oracle import meant_oracle as O
+    torch.manual_seed(0)
+    cores = min(os.cpu_count() or 1, 16)            # the 1-GPU box gives a 16-thread CPU share
+    torch.set_num_threads(cores)
+    m = O.meant(D, D, 4, IMG, IMG, P, L, NCLS, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C).eval()
+    O.fill_weights_(m, 1234)
+    rs = np.random.RandomState(99)
+    ids = torch.from_numpy(rs.randint(0, V, (1, L, S)).astype("int64"))
+    img = torch.from_numpy(rs.standard_normal((1, L, C, IMG, IMG)).astype("float32"))
+    mask = torch.ones(1, L, S)
+    mask[0, :, 400:] = 0
+    tgt = torch.tensor([1])
+    times = []
+    t_start = time.time()
+    for it in range(7):
+        t0 = time.time()
+        m.zero_grad(set_to_none=True)
+        O.cross_entropy_on_probs(m(ids, img, mask), tgt).backward()
+        dt = time.time() - t0
+        if it >= 2:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and len(times) >= 2:
+            break
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"CPU oracle (fp32 eager restatement pinned to the reference's golden vectors), same MEANT config "
+                      f"(lag=12, d=768, S=512, 224x224, E={E}), batch 1, fwd+CE+bwd, median of {len(times)} iterations after 2 warm-ups"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-per-gpu", type=int, default=128)
+    ap.add_argument("--encoders", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity-mode numerics)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import meant_amd
+    from meant_amd.parallel import GradReducer
+
+    timer = GemmTimer()
+    timer.install()
+    E, B = args.encoders, args.batch_per_gpu
+    model = build_model(E, dev)
+    model.train(not args.eval_mode)
+    if world > 1:                                   # identical replicas: broadcast rank 0's weights once
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    reducer = GradReducer(model.parameters(), bucket_mb=64.0)
+    tweets, images, mask, target = make_batch(B, rank, dev)
+
+    def step():
+        reducer.prepare()
+        out = model(tweets, images, mask)
+        loss = torch.nn.functional.cross_entropy(out, target)
+        loss.backward()
+        reducer.wait()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        sps = world * B * args.steps / elapsed
+        n, gf, gt = timer.summary()
+        achieved = gf / gt / 1e12 if gt > 0 else 0.0
+        roofline = {"kernel": "gemm_bf16_nt_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_timed": n, "avg_launch_ms": round(gt / max(n, 1) * 1e3, 4),
+                    "avg_launch_gflop": round(gf / max(n, 1) / 1e9, 2),
+                    "whole_step_mfma_frac": round(sps / world * flops_per_sample(E) / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        res = {"metric": "samples/sec fwd+bwd, MEANT lag=12 d=768", "value": round(sps, 2), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "full MEANT (tweet+image) fwd+CE+bwd, lag=12, d=768, 12 heads, seq=512, 224x224 p=16, "
+                                      f"E={E}, vocab 64001 (BASELINE.json configs[2]/[3])",
+                          "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "train_mode_dropout": not args.eval_mode, "grad_allreduce": world > 1,
+                          "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(E)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""Data parallelism for the MEANT path: one process per GPU, batch sharded, weights replicated,
+one bucketed gradient all-reduce per step over RCCL (torch.distributed backend "nccl" on ROCm)
+riding the xGMI mesh, overlapped with the rest of backward.
+
+What it replaces: the reference's only multi-GPU mechanism is single-process nn.DataParallel
+(pretrain_mlm.py:329-330, pretrain_mim.py:347-348), which re-broadcasts every weight and gathers
+every output through GPU 0 each step.  Samples are independent through the whole forward/backward
+(SURVEY.md 8e), so the only exchange the path needs is the gradient sum.
+
+Design for xGMI (point-to-point links, ring collectives are per-link bound): few large buckets.
+Parameters are packed, in reverse registration order (roughly the order their gradients become
+final), into flat fp32 buckets of `bucket_mb`; every p.grad is a VIEW into its bucket, so there is
+no flatten/unflatten copy.  A bucket's all-reduce is launched from the autograd hook of its last
+parameter to finish, asynchronously, while backward continues; `wait()` joins before the optimizer.
+The big embedding table (49 M of the 73.6 M parameters at V=64001) is its own bucket and, being the
+first layer, is reduced last.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "pending", "handle")
+
+    def __init__(self, flat, params):
+        self.flat, self.params, self.pending, self.handle = flat, params, 0, None
+
+
+class GradReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None,
+                 average: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
+        plist: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        seen, uniq = set(), []
+        for p in plist:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        uniq.reverse()
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets: List[_Bucket] = []
+        cur: List[torch.nn.Parameter] = []
+        cur_n = 0
+
+        def flush():
+            nonlocal cur, cur_n
+            if not cur:
+                return
+            flat = torch.zeros(cur_n, device=cur[0].device, dtype=torch.float32)
+            off = 0
+            for p in cur:
+                n = p.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+            self.buckets.append(_Bucket(flat, cur))
+            cur, cur_n = [], 0
+
+        for p in uniq:
+            assert p.dtype == torch.float32, "master weights / gradients are fp32"
+            if cur and (cur_n + p.numel() > cap or p.device != cur[0].device):
+                flush()
+            cur.append(p)
+            cur_n += p.numel()
+        flush()
+        self._owner = {}
+        for b in self.buckets:
+            for p in b.params:
+                self._owner[id(p)] = b
+                p.register_post_accumulate_grad_hook(self._hook)
+        self.prepare()
+
+    # -- per step ---------------------------------------------------------------------------
+    def prepare(self):
+        """zero the buckets (== zero_grad) and re-arm the hooks; call before each backward"""
+        for b in self.buckets:
+            b.flat.zero_()
+            b.pending = len(b.params)
+            b.handle = None
+            off = 0
+            for p in b.params:                      # keep .grad pointing into the bucket
+                n = p.numel()
+                if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * 4:
+                    p.grad = b.flat[off:off + n].view_as(p)
+                off += n
+
+    def _hook(self, p):
+        b = self._owner[id(p)]
+        b.pending -= 1
+        if b.pending == 0 and self.world > 1:
+            op = dist.ReduceOp.SUM
+            b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+
+    def wait(self):
+        """join the outstanding all-reduces (parameters that received no gradient this step still get
+        their bucket reduced here) and apply the 1/world average"""
+        for b in self.buckets:
+            if self.world > 1:
+                if b.handle is None:
+                    b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.handle.wait()
+                if self.average:
+                    b.flat.mul_(1.0 / self.world)
+
+    @property
+    def num_buckets(self) -> int:
+        return len(self.buckets)
+
+    def grad_bytes(self) -> int:
+        return sum(b.flat.numel() for b in self.buckets) * 4
+
+
+def shard_batch(total: int, rank: int, world: int):
+    """rows [lo, hi) of the global batch owned by `rank` (rank r takes rows [128r, 128r+128))"""
+    per = total // world
+    assert per * world == total, "global batch must divide evenly over the ranks"
+    return rank * per, (rank + 1) * per
