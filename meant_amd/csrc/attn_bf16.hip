@@ -23,6 +23,7 @@
 // arithmetic intensity (256 / 98 FLOP/B) is below the machine balance, and the exp() work per score keeps
 // the VALU, not the MFMA, on the critical path for Dh=64.
 #include "internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -39,6 +40,10 @@ __device__ __forceinline__ int swz(int r) { return ((r & 2) << 1) | ((r >> 2) & 
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ void glds4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 4, 0, 0);
 }
 
 // stage a [64 rows][64 cols] bf16 tile: rows row0.. (clamped to nrows-1) of a matrix with row stride ld.
@@ -65,20 +70,27 @@ __device__ __forceinline__ bf16x8 frag_row(const char* tile, int row0, int ks, i
 
 // transposed fragment: lane (col = lane&31, h = lane>>5) gets, for j = 0..7,
 // tile[krow0 + 8*(j>>2) + 4h + (j&3)][col0 + col]   -- the k order of an accumulator reused as an operand.
-__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int krow0, int col0, int lane) {
-  const int h = lane >> 5;
-  const int i16 = lane & 15;
-  const int q = i16 >> 2, p = i16 & 3;
-  const int col = col0 + ((lane >> 4) & 1) * 16 + 4 * p;     // first of this lane's 4 columns
-  const int c = col >> 3, sub = (col & 7) * 2;
-  bf16x8 out;
+// Issued as inline-asm ds_read_b64_tr_b16 (see common.h: the builtin makes hipcc drain the DMA queue).
+// Because the swizzle XORs the chunk index with bits of the row, the per-lane address is precomputed for
+// u = j>>2 in {0,1} and the 32-column block b in {0,1}; krow0 (a multiple of 16 rows) is an immediate.
+struct TrOff { unsigned o[2][2]; };               // [u][b], byte offsets inside a tile
+__device__ __forceinline__ TrOff make_troff(int lane) {
+  TrOff t;
+  const int h = lane >> 5, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int r = krow0 + 8 * u + 4 * h + q;
-    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + r * 128 + ((c ^ swz(r)) << 4) + sub));
-    out[4 * u + 0] = v[0]; out[4 * u + 1] = v[1]; out[4 * u + 2] = v[2]; out[4 * u + 3] = v[3];
-  }
-  return out;
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = 8 * u + 4 * h + q;
+      const int col = 32 * b + ((lane >> 4) & 1) * 16 + 4 * p;
+      t.o[u][b] = (unsigned)(r * 128 + ((((col >> 3)) ^ swz(r)) << 4) + (col & 7) * 2);
+    }
+  return t;
+}
+template <int KROW0>
+__device__ __forceinline__ void tr_issue(unsigned tile_addr, const TrOff& t, int b, u32x2& lo, u32x2& hi) {
+  lo = lds_read_tr16<KROW0 * 128>(tile_addr + t.o[0][b]);
+  hi = lds_read_tr16<KROW0 * 128>(tile_addr + t.o[1][b]);
 }
 
 // accumulator (32 keys x 32 queries, fp32) -> two bf16 B-operand fragments (k-steps of 16 keys)
@@ -161,17 +173,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
     for (int e = 0; e < 16; ++e) oacc[b][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
   auto stage = [&](int t, int buf) {
     stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
     stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
-    if (tid < 64) {
-      const int key = t * KV_TILE + tid;
-      float b = 0.f;
-      if (key >= S) b = -INFINITY;
-      else if (km) b = (1.0f - km[key]) * -1e9f;
-      bias_s[buf * 64 + tid] = b;
+    if (km && wave == 0) {                           // the tile's 64 key-mask floats
+      int key = t * KV_TILE + lane;
+      key = key < S ? key : S - 1;
+      glds4(km + key, bias_s + buf * 64);
     }
   };
+  const TrOff troff = make_troff(lane);
 
   stage(0, 0);
   __syncthreads();
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
           sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc[sb], 0, 0, 0);
       }
       // scale, mask, running max
-      const bool need_bias = (km != nullptr) || (k0 + KV_TILE > S);
+      const bool tail = k0 + KV_TILE > S;
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);   // tile touches the diagonal for some query of this wave
       float tmax = -INFINITY;
 #pragma unroll
@@ -203,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
         for (int e = 0; e < 16; ++e) {
           const int kl = 32 * sb + acc_row(e, lane);
           float s = sacc[sb][e] * a.scale;
-          if (need_bias) s += bias_s[buf * 64 + kl];
-          if (diag && (k0 + kl > myq)) s = -INFINITY;
+          if (km) s += (1.0f - bias_s[buf * 64 + kl]) * -1e9f;
+          if ((diag && (k0 + kl > myq)) || (tail && (k0 + kl >= S))) s = -INFINITY;
           sacc[sb][e] = s;
           tmax = fmaxf(tmax, s);
         }
@@ -229,16 +241,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
       // O^T += V^T P^T
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
+      const unsigned vaddr = lds_addr(Vt);
+      auto pv = [&](auto SB) {
+        constexpr int sb = decltype(SB)::value;
+        u32x2 lo[2][2], hi[2][2];
+        tr_issue<32 * sb>(vaddr, troff, 0, lo[0][0], hi[0][0]);
+        tr_issue<32 * sb>(vaddr, troff, 1, lo[0][1], hi[0][1]);
+        tr_issue<32 * sb + 16>(vaddr, troff, 0, lo[1][0], hi[1][0]);
+        tr_issue<32 * sb + 16>(vaddr, troff, 1, lo[1][1], hi[1][1]);
         bf16x8 pf[2];
         acc_to_frags(sacc[sb], pf[0], pf[1]);
+        lds_wait_all();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, 32 * sb + 16 * s2, 32 * b, lane), pf[s2], oacc[b], 0, 0, 0);
-      }
+            oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), pf[s2], oacc[b], 0, 0, 0);
+      };
+      pv(std::integral_constant<int, 0>{});
+      pv(std::integral_constant<int, 1>{});
     }
     __syncthreads();
   }
@@ -317,17 +338,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[b][e] = 0.f;
 
+  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
   auto stage = [&](int t, int buf) {
     stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
     stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
-    if (tid < 64) {
-      const int key = t * KV_TILE + tid;
-      float b = 0.f;
-      if (key >= S) b = -INFINITY;
-      else if (km) b = (1.0f - km[key]) * -1e9f;
-      bias_s[buf * 64 + tid] = b;
+    if (km && wave == 0) {                           // the tile's 64 key-mask floats
+      int key = t * KV_TILE + lane;
+      key = key < S ? key : S - 1;
+      glds4(km + key, bias_s + buf * 64);
     }
   };
+  const TrOff troff = make_troff(lane);
 
   stage(0, 0);
   __syncthreads();
@@ -339,10 +360,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     if (active && q0 < S) {
       const char* Kt = smem + buf * 2 * TILE_B;
       const char* Vt = Kt + TILE_B;
-      const bool need_bias = (km != nullptr) || (k0 + KV_TILE > S);
+      const bool tail = k0 + KV_TILE > S;
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
+      const unsigned kaddr = lds_addr(Kt);
+      auto body = [&](auto SB) {
+        constexpr int sb = decltype(SB)::value;
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
@@ -355,19 +377,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
         for (int e = 0; e < 16; ++e) {
           const int kl = 32 * sb + acc_row(e, lane);
           float s = sacc[e] * a.scale;
-          if (need_bias) s += bias_s[buf * 64 + kl];
+          if (km) s += (1.0f - bias_s[buf * 64 + kl]) * -1e9f;
           float p = __expf((s - m_q) - logl_q);
-          if (diag && (k0 + kl > myq)) p = 0.f;
+          if ((diag && (k0 + kl > myq)) || (tail && (k0 + kl >= S))) p = 0.f;
           sacc[e] = p * (dpacc[e] - delta) * a.scale;          // dS^T
         }
+        u32x2 lo[2][2], hi[2][2];
+        tr_issue<32 * sb>(kaddr, troff, 0, lo[0][0], hi[0][0]);
+        tr_issue<32 * sb>(kaddr, troff, 1, lo[0][1], hi[0][1]);
+        tr_issue<32 * sb + 16>(kaddr, troff, 0, lo[1][0], hi[1][0]);
+        tr_issue<32 * sb + 16>(kaddr, troff, 1, lo[1][1], hi[1][1]);
         bf16x8 dsf[2];
         acc_to_frags(sacc, dsf[0], dsf[1]);
+        lds_wait_all();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            dqacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, 32 * sb + 16 * s2, 32 * b, lane), dsf[s2], dqacc[b], 0, 0, 0);
-      }
+            dqacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), dsf[s2], dqacc[b], 0, 0, 0);
+      };
+      body(std::integral_constant<int, 0>{});
+      body(std::integral_constant<int, 1>{});
     }
     __syncthreads();
   }
@@ -417,18 +447,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
   const int t0 = a.causal ? kb0 / 64 : 0;            // first query tile that can see this block's keys
   const int nt = (S + 63) / 64;
 
+  // per-tile statistics by DMA too: st[0..127] = interleaved (m, log l) pairs of the 64 queries, st[128..191] = delta
   auto stage = [&](int t, int buf) {
     stage64(base, ld, t * 64, S, smem + buf * 2 * TILE_B, wave, lane);
     stage64(dO, D, t * 64, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
-    if (tid < 64) {
-      int q = t * 64 + tid;
-      q = q < S ? q : S - 1;
+    if (wave == 0) {
       float* st = stats + buf * 192;
-      st[tid] = lse[q * 2];
-      st[64 + tid] = lse[q * 2 + 1];
-      st[128 + tid] = dl[q];
+      const int last = 2 * S - 1;
+      int i0 = t * 128 + lane, i1 = t * 128 + 64 + lane, qd = t * 64 + lane;
+      i0 = i0 < last ? i0 : last;
+      i1 = i1 < last ? i1 : last;
+      qd = qd < S ? qd : S - 1;
+      glds4(lse + i0, st);
+      glds4(lse + i1, st + 64);
+      glds4(dl + qd, st + 128);
     }
   };
+  const TrOff troff = make_troff(lane);
 
   if (t0 < nt) {
     stage(t0, 0);
@@ -443,10 +478,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
       const char* Qt = smem + buf * 2 * TILE_B;
       const char* dOt = Qt + TILE_B;
       const float* st = stats + buf * 192;
-#pragma unroll
-      for (int sq = 0; sq < 2; ++sq) {
+      const unsigned qaddr = lds_addr(Qt), doaddr = lds_addr(dOt);
+      auto body = [&](auto SQ) {
+        constexpr int sq = decltype(SQ)::value;
         const int qs0 = qt0 + 32 * sq;
-        if (a.causal && qs0 + 31 < key0) continue;   // wave-uniform
+        if (a.causal && qs0 + 31 < key0) return;     // wave-uniform
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
@@ -460,9 +496,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int ql = 32 * sq + 8 * g4 + 4 * (lane >> 5);          // 4 consecutive local query rows
-          const f32x4 mv = *reinterpret_cast<const f32x4*>(st + ql);
-          const f32x4 lv = *reinterpret_cast<const f32x4*>(st + 64 + ql);
+          const f32x4 ml0 = *reinterpret_cast<const f32x4*>(st + 2 * ql);       // m0 l0 m1 l1
+          const f32x4 ml1 = *reinterpret_cast<const f32x4*>(st + 2 * ql + 4);   // m2 l2 m3 l3
           const f32x4 dv = *reinterpret_cast<const f32x4*>(st + 128 + ql);
+          const float mv[4] = {ml0[0], ml0[2], ml1[0], ml1[2]};
+          const float lv[4] = {ml0[1], ml0[3], ml1[1], ml1[3]};
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             const int e = g4 * 4 + e4;
@@ -474,17 +512,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
             dpacc[e] = p * (dpacc[e] - dv[e4]) * a.scale;
           }
         }
+        u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
+        tr_issue<32 * sq>(doaddr, troff, 0, dlo[0][0], dhi[0][0]);
+        tr_issue<32 * sq>(doaddr, troff, 1, dlo[0][1], dhi[0][1]);
+        tr_issue<32 * sq + 16>(doaddr, troff, 0, dlo[1][0], dhi[1][0]);
+        tr_issue<32 * sq + 16>(doaddr, troff, 1, dlo[1][1], dhi[1][1]);
+        tr_issue<32 * sq>(qaddr, troff, 0, qlo[0][0], qhi[0][0]);
+        tr_issue<32 * sq>(qaddr, troff, 1, qlo[0][1], qhi[0][1]);
+        tr_issue<32 * sq + 16>(qaddr, troff, 0, qlo[1][0], qhi[1][0]);
+        tr_issue<32 * sq + 16>(qaddr, troff, 1, qlo[1][1], qhi[1][1]);
         bf16x8 pf[2], dsf[2];
         acc_to_frags(sacc, pf[0], pf[1]);
         acc_to_frags(dpacc, dsf[0], dsf[1]);
+        lds_wait_all();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            dvacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOt, 32 * sq + 16 * s2, 32 * b, lane), pf[s2], dvacc[b], 0, 0, 0);
-            dkacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 32 * sq + 16 * s2, 32 * b, lane), dsf[s2], dkacc[b], 0, 0, 0);
+            dvacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[b], 0, 0, 0);
+            dkacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[b], 0, 0, 0);
           }
-      }
+      };
+      body(std::integral_constant<int, 0>{});
+      body(std::integral_constant<int, 1>{});
     }
     __syncthreads();
   }

@@ -102,6 +102,32 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// ---- LDS helpers -------------------------------------------------------------------------------
+// 32-bit LDS byte address of a pointer into __shared__ memory
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+}
+// ds_read_b64_tr_b16 issued as inline asm.  Why not the builtin: with global_load_lds DMA in flight hipcc
+// (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of every builtin transposed LDS read, which drains the
+// prefetch of the next tile before the current one is consumed.  The asm form is invisible to that pass;
+// the caller owns the ordering: lds_wait_all() (s_waitcnt lgkmcnt(0) + a scheduling fence) must sit between
+// these reads and the first use of their results, and the DMA that filled the tile must have been retired
+// by a vmcnt wait + barrier before (the kernels do that once per tile).
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void lds_wait_all() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 pack_tr(u32x2 lo, u32x2 hi) {
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 #define DISPATCH_DTYPE(dtype, T, ...)                                           \
   do {                                                                          \
     if ((dtype) == MEANT_F32) { using T = float; __VA_ARGS__; }                 \

@@ -24,6 +24,7 @@
 //     residual applied in fp32 and a single rounding.
 // Roofline: MFMA-bound (dense bf16 peak 2.5 PFLOP/s); algorithmic FLOPs 2*M*N*K per launch.
 #include "internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -177,6 +178,154 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Args a, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT kernel, 256 x 256 block tile, 512 threads = 8 waves (2 along M x 4 along N), 128 x 64 per wave.
+// Why: the 128 x 128 kernel is bound by the L2 -> LDS load path (~40 GB/s per CU sustained = 64 FLOP per
+// loaded byte x 40 GB/s x 256 CUs = 650 TFLOP/s, exactly what it measures); a 256 x 256 tile needs half the
+// operand bytes per FLOP.  One block per CU (128 KiB of LDS: 2 stages x (A 32 KiB + B 32 KiB)), 2 waves/SIMD.
+constexpr int B2 = 256;
+constexpr int T2_BYTES = B2 * BK * 2;              // 32 KiB per operand per stage
+
+// 32 pieces of 1 KiB (8 rows each) per tile; wave w issues pieces 4w .. 4w+3
+__device__ __forceinline__ void nt256_stage(const bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                             char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int64_t gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;
+    glds16(g + gr * ld + k0 + c * 8, lds_tile + piece * 1024);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = id / ntn, tn = id - tm * ntn;
+  const int64_t m0 = (int64_t)tm * B2, n0 = (int64_t)tn * B2;
+  const int nk = (int)(a.K / BK);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  nt256_stage(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  nt256_stage(a.B, a.ldb, n0, a.N, 0, smem + T2_BYTES, wave, lane);
+  __syncthreads();
+
+  const int frow = lane & 15, fkg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * 2 * T2_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * T2_BYTES;
+    if (kt + 1 < nk) {
+      nt256_stage(a.A, a.lda, m0, a.M, (int64_t)(kt + 1) * BK, nxt, wave, lane);
+      nt256_stage(a.B, a.ldb, n0, a.N, (int64_t)(kt + 1) * BK, nxt + T2_BYTES, wave, lane);
+    }
+    const char* At = cur + (wm * 128) * 128;
+    const char* Bt = cur + T2_BYTES + (wn * 64) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[8], bfr[4];
+      const int c = ks * 4 + fkg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(At + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = j * 16 + frow;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: 4 passes of 64 rows through LDS (fp32 [64][260]) ---------------------------------
+  constexpr int LDC = B2 + 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int cc = (tid & 31) * 8;
+  const int64_t n = n0 + cc;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = (a.bias && n + e < a.N) ? a.bias[n + e] : 0.f;
+  const bool vec_ok = (n + 8 <= a.N) && ((a.ldc & 7) == 0) && (!a.residual || (a.ldr & 7) == 0);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (pass) __syncthreads();
+    if (wm == (pass >> 1)) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = (pass & 1) * 4 + ii;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            Cs[(ii * 16 + fkg * 4 + e) * LDC + wn * 64 + j * 16 + frow] = acc[i][j][e];
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int q = 0; q < 4; ++q) {
+      const int r = q * 16 + (tid >> 5);
+      const int64_t m = m0 + pass * 64 + r;
+      if (m >= a.M || n >= a.N) continue;
+      float v[8];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
+      if (vec_ok) {
+        if (a.preact) {
+          bf16x8 p;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) p[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = p;
+        }
+        if (a.epilogue & MEANT_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (a.epilogue & MEANT_EPI_SIGMOID) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+        }
+        if (a.residual) {
+          const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
+      } else {
+        for (int e = 0; e < 8 && n + e < a.N; ++e) {
+          float x = v[e];
+          if (a.preact) a.preact[m * a.ldc + n + e] = (bf16)x;
+          if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf(x);
+          if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
+          if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
+          a.C[m * a.ldc + n + e] = (bf16)x;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN kernel: dW[n][k] += sum_m dY[m][n] X[m][k].  LDS tiles are [64 m][128 cols] (256-byte rows).
 constexpr int TN_BKM = 64;
 constexpr int TN_TILE_BYTES = TN_BKM * 128 * 2;    // 16 KiB
@@ -190,15 +339,10 @@ __device__ __forceinline__ void tn_stage(const bf16* __restrict__ g, int64_t ld,
     const int r = piece * 4 + (lane >> 4);
     const int slot = lane & 15;
     const int c = slot ^ ((r & 3) << 2);
-    const int64_t gm = m0 + r;
+    const int64_t gm = m0 + r;                     // always < mend: the launcher hands over whole 64-row tiles only
     int64_t gc = col0 + c * 8;
     gc = gc + 8 <= ncols ? gc : (ncols >= 8 ? ncols - 8 : 0);     // column clamp (those outputs are discarded)
-    if (gm < mend) {
-      glds16(g + gm * ld + gc, lds_tile + piece * 1024);
-    } else {
-      // rows past the end of the token axis must contribute zero: write the slot this lane would have DMA'd
-      *reinterpret_cast<u32x4*>(lds_tile + piece * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
+    glds16(g + gm * ld + gc, lds_tile + piece * 1024);
   }
 }
 
@@ -288,6 +432,137 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const bf16* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel, 256 x 256 output tile, 8 waves (2 along n x 4 along k), 128 x 64 per wave, 64 token rows per
+// stage ([64 m][256] tiles, 512-byte rows, 32 KiB each, 2 stages = 128 KiB).  Same load-path argument as
+// the 256 x 256 NT kernel.  The bias gradient (column sums of dY) is accumulated from the dY fragments
+// the k-tile-0 blocks already hold -- no separate pass over dY.
+constexpr int TN2_TILE = TN_BKM * 256 * 2;         // 32 KiB
+
+__device__ __forceinline__ void tn256_stage(const bf16* __restrict__ g, int64_t ld, int64_t m0, int64_t mend, int64_t col0,
+                                             char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;                // 1 KiB = 2 rows of 512 B
+    const int r = piece * 2 + (lane >> 5);
+    const int slot = lane & 31;
+    const int c = slot ^ ((r & 3) << 2);
+    const int64_t gm = m0 + r;                     // always < mend (whole 64-row tiles only)
+    glds16(g + gm * ld + col0 + c * 8, lds_tile + piece * 1024);
+  }
+}
+
+// per-lane byte offset (inside a [64][256] tile) of the transposed-read address for the 32-column block at col0:
+// row 8h + q of the first k-step, this lane's 4 columns; k-step ks / half t add (16 ks + 4 t) * 512 as an immediate.
+__device__ __forceinline__ unsigned tn256_lane_off(int col0, int lane) {
+  const int h = lane >> 5, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int cbyte = (col0 + ((lane >> 4) & 1) * 16 + 4 * p) * 2;
+  const int r = 8 * h + q;                          // (r & 3) == q for every (ks, t)
+  return (unsigned)(r * 512 + (((cbyte >> 4) ^ (q << 2)) << 4) + (cbyte & 15));
+}
+template <int KS>
+__device__ __forceinline__ void tn256_frag_issue(unsigned addr, u32x2& lo, u32x2& hi) {
+  lo = lds_read_tr16<KS * 8192>(addr);
+  hi = lds_read_tr16<KS * 8192 + 2048>(addr);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
+                                                                  int64_t ldx, float* __restrict__ dW, float* __restrict__ dbias,
+                                                                  int64_t M, int64_t N, int64_t K, int ntn, int ntk,
+                                                                  int64_t rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 2, wk = wave & 3;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = bid % (ntn * ntk);
+  const int split = bid / (ntn * ntk);
+  const int tn = tile / ntk, tk = tile - tn * ntk;
+  const int64_t n0 = (int64_t)tn * 256, k0 = (int64_t)tk * 256;
+  const int64_t mbeg = (int64_t)split * rows_per_split;
+  const int64_t mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  if (mbeg >= mend) return;
+  const int nt = (int)((mend - mbeg + TN_BKM - 1) / TN_BKM);
+  const bool do_bias = (dbias != nullptr) && (tk == 0) && (wk == 0);      // wave-uniform
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = tn256_lane_off(wn * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = tn256_lane_off(wk * 64 + j * 32, lane);
+
+  tn256_stage(dY, lddy, mbeg, mend, n0, smem, wave, lane);
+  tn256_stage(X, ldx, mbeg, mend, k0, smem + TN2_TILE, wave, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * 2 * TN2_TILE;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TN2_TILE;
+    if (t + 1 < nt) {
+      tn256_stage(dY, lddy, mbeg + (int64_t)(t + 1) * TN_BKM, mend, n0, nxt, wave, lane);
+      tn256_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, nxt + TN2_TILE, wave, lane);
+    }
+    const unsigned cbase = lds_addr(cur);
+    auto kstep = [&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      u32x2 alo[4], ahi[4], blo[2], bhi[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tn256_frag_issue<ks>(cbase + aoff[i], alo[i], ahi[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tn256_frag_issue<ks>(cbase + TN2_TILE + boff[j], blo[j], bhi[j]);
+      lds_wait_all();
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = pack_tr(alo[i], ahi[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = pack_tr(blo[j], bhi[j]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[i] += (float)af[i][e];
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    kstep(std::integral_constant<int, 0>{});
+    kstep(std::integral_constant<int, 1>{});
+    kstep(std::integral_constant<int, 2>{});
+    kstep(std::integral_constant<int, 3>{});
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t kcol = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t nrow = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        atomicAdd(dW + nrow * K + kcol, acc[i][j][e]);
+      }
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s2 = csum[i] + __shfl_xor(csum[i], 32, 64);
+      if (lane < 32) atomicAdd(dbias + n0 + wn * 128 + i * 32 + lane, s2);
+    }
+  }
+}
+
 }  // namespace
 
 int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
@@ -295,6 +570,18 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_REQUIRE(a.K % BK == 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: K=%lld must be a multiple of %d (use the fp32 tier otherwise)", (long long)a.K, BK);
   MEANT_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0 && meant_aligned16(a.A) && meant_aligned16(a.B), MEANT_ERR_ARG,
                 "gemm_bf16_nt: operands must be 16-byte aligned with row strides that are multiples of 8");
+  static bool attr256_set = false;
+  if (!attr256_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_BYTES);
+    attr256_set = true;
+  }
+  if (a.M >= 1024 && a.N % 256 == 0) {              // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP)
+    const int64_t ntm2 = ceil_div(a.M, B2), ntn2 = a.N / B2;
+    MEANT_REQUIRE(ntm2 * ntn2 < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
+    hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+    MEANT_LAUNCH_CHECK("gemm_bf16_nt256");
+    return MEANT_OK;
+  }
   const int64_t ntm = ceil_div(a.M, BM), ntn = ceil_div(a.N, BN);
   MEANT_REQUIRE(ntm * ntn < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
   const size_t lds = 128 * (128 + 4) * sizeof(float);   // 67584 B: covers the 64 KiB of staging buffers too
@@ -308,11 +595,50 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   return MEANT_OK;
 }
 
+static int tn_tail(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N, int64_t K,
+                   hipStream_t stream) {
+  // fewer than 64 trailing token rows: exact generic kernel, accumulating into the same dW / dbias
+  GemmF32Args g{};
+  g.in_dtype = MEANT_BF16; g.out_dtype = MEANT_F32;
+  g.A = dY; g.B = X; g.C = dW;
+  g.M = N; g.N = K; g.K = M; g.nb1 = 1; g.nb2 = 1;
+  g.sA[2] = 1; g.sA[3] = lddy; g.sB[2] = ldx; g.sB[3] = 1; g.sC[2] = K; g.sC[3] = 1;
+  g.alpha = 1.f; g.accumulate = 1;
+  int rc = gemm_f32_launch(g, stream);
+  if (rc) return rc;
+  if (dbias) return colsum_launch(dY, lddy, dbias, M, N, MEANT_BF16, 1, stream);
+  return MEANT_OK;
+}
+
 int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N,
                         int64_t K, hipStream_t stream) {
   MEANT_REQUIRE((lddy % 8) == 0 && (ldx % 8) == 0 && meant_aligned16(dY) && meant_aligned16(X), MEANT_ERR_ARG,
                 "gemm_bf16_tn: operands must be 16-byte aligned with row strides that are multiples of 8");
   MEANT_REQUIRE(N >= 8 && K >= 8, MEANT_ERR_UNSUPPORTED, "gemm_bf16_tn: N and K must be >= 8");
+  const int64_t Mtail = M % TN_BKM;
+  if (Mtail) {
+    const int64_t Mmain = M - Mtail;
+    int rc = tn_tail(dY + Mmain * lddy, lddy, X + Mmain * ldx, ldx, dW, dbias, Mtail, N, K, stream);
+    if (rc || Mmain == 0) return rc;
+    M = Mmain;
+  }
+  if (N % 256 == 0 && K % 256 == 0 && M >= 4096) {
+    const int64_t ntn2 = N / 256, ntk2 = K / 256;
+    int64_t splits2 = ceil_div(512, ntn2 * ntk2);            // ~2 blocks per CU over the launch, 1 resident
+    const int64_t max2 = ceil_div(M, 512);
+    if (splits2 > max2) splits2 = max2;
+    int64_t rows2 = ceil_div(ceil_div(M, splits2), TN_BKM) * TN_BKM;
+    splits2 = ceil_div(M, rows2);
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN2_TILE);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3((unsigned)(ntn2 * ntk2 * splits2)), dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx,
+                       dW, dbias, M, N, K, (int)ntn2, (int)ntk2, rows2);
+    MEANT_LAUNCH_CHECK("gemm_bf16_tn256");
+    return MEANT_OK;
+  }
   const int64_t ntn = ceil_div(N, 128), ntk = ceil_div(K, 128);
   // split the token axis so that the launch has >= ~4 blocks per CU; each split is a multiple of 64 rows
   int64_t splits = ceil_div(1024, ntn * ntk);

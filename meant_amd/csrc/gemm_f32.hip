@@ -144,7 +144,7 @@ int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, 
   if (!accumulate) {
     if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { meant_set_error("colsum: memset failed"); return MEANT_ERR_LAUNCH; }
   }
-  int64_t strips = ceil_div(M, 512);
+  int64_t strips = ceil_div(M, 64);
   if (strips > 512) strips = 512;
   DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)ceil_div(N, 64), (unsigned)strips), dim3(256), 0, stream, (const T*)x, ldx, out, M, N));
   MEANT_LAUNCH_CHECK("colsum");

@@ -4,7 +4,7 @@
 //   butterfly reduction over the wave, gain-gradient partials reduced per block then by a second
 //   tiny kernel (no atomics -> bitwise reproducible).
 // Reference semantics: utils/rms_norm.py:40-57 (eps added to the RMS, outside the sqrt).
-#include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -298,10 +298,7 @@ extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* sca
                  hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
                                     (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, eps, drop_p, seed));
   MEANT_LAUNCH_CHECK("rmsnorm_bwd");
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, dscale, nb, (int)d);
-  MEANT_LAUNCH_CHECK("rmsnorm_bwd/colreduce");
-  return MEANT_OK;
+  return colsum_launch(workspace, d, dscale, nb, d, MEANT_F32, 0, (hipStream_t)stream);
 }
 
 extern "C" int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
@@ -326,10 +323,7 @@ extern "C" int meant_layernorm_bwd(const void* dy, const void* x, const float* g
                  hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
                                     (const T*)x, gamma, stats, (T*)dx, (float*)workspace, rows, (int)d));
   MEANT_LAUNCH_CHECK("layernorm_bwd");
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, dgamma, nb, (int)d);
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace + (size_t)nb * d, dbeta, nb, (int)d);
-  MEANT_LAUNCH_CHECK("layernorm_bwd/colreduce");
-  return MEANT_OK;
+  int rc = colsum_launch(workspace, d, dgamma, nb, d, MEANT_F32, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  return colsum_launch((const float*)workspace + (size_t)nb * d, d, dbeta, nb, d, MEANT_F32, 0, (hipStream_t)stream);
 }

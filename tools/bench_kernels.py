@@ -40,15 +40,18 @@ def bench_gemm():
         ref = (x[:256].float() @ w.float().t() + b)
         err = (y[:256].float() - ref).abs().max().item()
         assert err < 0.1, err
-    print("== bf16 TN GEMM  dW[N,K] += dY[M,N]^T X[M,K]")
+    print("== bf16 TN GEMM  dW[N,K] += dY[M,N]^T X[M,K], db += colsum(dY)")
     for (M, N, K) in [(6144 * 16, 768, 768), (6144 * 16, 2304, 768), (6144 * 128, 768, 768)]:
         dy = torch.randn(M, N, device=dev).bfloat16()
         x = torch.randn(M, K, device=dev).bfloat16()
         dw = torch.zeros(N, K, device=dev)
-        f = lambda: check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), None, M, N, K, BF16, st()))
+        db = torch.zeros(N, device=dev)
+        f = lambda: check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, N, K, BF16, st()))
         t = timeit(f)
         print(f"  M={M:7d} N={N:5d} K={K:5d}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TFLOP/s")
-        dw.zero_(); f(); torch.cuda.synchronize()
+        dw.zero_(); db.zero_(); f(); torch.cuda.synchronize()
+        refb = dy.float().sum(0)
+        assert ((db - refb).abs().max() / refb.abs().max()).item() < 1e-3
         ref = dy[:, :64].float().t() @ x.float()
         rel = ((dw[:64] - ref).abs().max() / ref.abs().max()).item()
         assert rel < 1e-2, rel
