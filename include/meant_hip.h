@@ -58,11 +58,15 @@ int meant_num_cus(void);
  * in backward from (seed, element index); p == 0 disables it. */
 int meant_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rinv, int64_t rows, int64_t d,
                       float eps, float drop_p, uint64_t seed, int dtype, void* stream);
-/* dx: act [rows, d]; dscale: float [d] (overwritten); workspace: float [meant_rmsnorm_bwd_ws(d)] */
+/* dx: act [rows, d]; dscale: float [d] (overwritten); workspace: meant_rmsnorm_bwd_ws(rows, d) bytes.
+ * Optional fusions (NULL to disable): dres act [rows, d] is added to dx (the gradient of the residual
+ * branch that shares x, meant/meant.py:71,74); gelu_pre act [rows, d]: x was gelu(gelu_pre), and dx is
+ * multiplied by gelu'(gelu_pre) so that it is the gradient w.r.t. gelu_pre (meant/meant.py:64). */
 size_t meant_rmsnorm_bwd_ws(int64_t rows, int64_t d);
 int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx,
                       float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed,
-                      int dtype, void* workspace, size_t workspace_bytes, void* stream);
+                      const void* dres, const void* gelu_pre, int dtype, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* ---- LayerNorm (heads of meant_vision / meant_tweet) ----- meant/meant_vision.py:147
  * stats: float [rows, 2] (mean, rstd). */

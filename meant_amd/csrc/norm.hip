@@ -1,8 +1,10 @@
 // K1: RMSNorm / LayerNorm forward + backward.  HBM-bound streaming kernels.
 //   one 64-lane wavefront per row, 16-byte (8-element bf16 / 2x16-byte f32) loads, the row kept in
 //   registers between the reduction and the normalisation (one read + one write per element),
-//   butterfly reduction over the wave, gain-gradient partials reduced per block then by a second
-//   tiny kernel (no atomics -> bitwise reproducible).
+//   butterfly reduction over the wave, gain-gradient partials reduced per block then summed by a strip
+//   kernel.  The backward optionally folds in the two elementwise passes that surround it in the encoder:
+//   the add of the gradient that arrives through the residual branch sharing x, and the GELU derivative
+//   when x = gelu(pre) (meant/meant.py:64,107).
 // Reference semantics: utils/rms_norm.py:40-57 (eps added to the RMS, outside the sqrt).
 #include "internal.h"
 
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ rinv, T* __restrict__ dx,
                                                                     float* __restrict__ partial, int64_t rows, int d,
-                                                                    float eps, float drop_p, uint64_t seed) {
+                                                                    float eps, float drop_p, uint64_t seed,
+                                                                    const T* __restrict__ dres, const T* __restrict__ gelu_pre) {
   __shared__ float red[4][512];   // reused per chunk: [wave][64 lanes * 8]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
@@ -114,6 +117,16 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
         Vec8<T> o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o.set(i, r * gd[c][i] - k * xv[c].get(i));
+        if (dres) {                                  // gradient arriving through the residual branch that shares x
+          const Vec8<T> rv = load8<T>(dres + row * d + ch * 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o.set(i, o.get(i) + rv.get(i));
+        }
+        if (gelu_pre) {                              // x = gelu(pre): chain through the activation in the same pass
+          const Vec8<T> pv = load8<T>(gelu_pre + row * d + ch * 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o.set(i, o.get(i) * gelu_erf_grad(pv.get(i)));
+        }
         store8<T>(dxr + ch * 8, o);
       }
     }
@@ -288,15 +301,17 @@ extern "C" int meant_rmsnorm_fwd(const void* x, const float* scale, void* y, flo
 extern "C" size_t meant_rmsnorm_bwd_ws(int64_t rows, int64_t d) { return (size_t)norm_blocks(rows) * d * sizeof(float) * 2; }
 
 extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx,
-                                 float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed, int dtype,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed,
+                                 const void* dres, const void* gelu_pre, int dtype, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd: null pointer");
   MEANT_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd: unsupported d=%lld", (long long)d);
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd: workspace too small");
   const int nb = norm_blocks(rows);
   DISPATCH_DTYPE(dtype, T,
                  hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
-                                    (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, eps, drop_p, seed));
+                                    (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, eps, drop_p, seed,
+                                    (const T*)dres, (const T*)gelu_pre));
   MEANT_LAUNCH_CHECK("rmsnorm_bwd");
   return colsum_launch(workspace, d, dscale, nb, d, MEANT_F32, 0, (hipStream_t)stream);
 }

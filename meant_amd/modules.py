@@ -236,11 +236,12 @@ class visionEncoder(nn.Module):
 
     def forward(self, input):
         e, e2 = self.encode, self.encode2
-        h = e[1](e[0](input))
-        h = e[3](e[2](h))
-        x1 = e[4](h, residual=input)
-        h = e2[1](e2[0](x1), epilogue=EPI_GELU)
-        return e2[4](e2[3](h), residual=x1)
+        n, res = ops.rmsnorm_fork(input, e[0].scale, e[0].eps)      # residual gradient is folded into this norm's backward
+        h = e[3](e[2](e[1](n)))
+        x1 = e[4](h, residual=res)
+        n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
+        h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
+        return e2[4](h, residual=res)
 
 
 class languageEncoder(nn.Module):
@@ -259,13 +260,13 @@ class languageEncoder(nn.Module):
         e, e2 = self.encode, self.encode2
         p1 = e[4].p if self.training else 0.0
         p2 = e2[4].p if self.training else 0.0
-        h = e[1](e[0](input))
-        h = e[2](h, attention_mask)
+        n, res = ops.rmsnorm_fork(input, e[0].scale, e[0].eps)
+        h = e[2](e[1](n), attention_mask)
         h = e[3](h, drop_p=p1, seed=_seed() if p1 > 0 else 0)
-        x1 = e[5](h, residual=input)
-        h = e2[1](e2[0](x1), epilogue=EPI_GELU)
-        h = e2[3](h, drop_p=p2, seed=_seed() if p2 > 0 else 0)
-        return e2[5](h, residual=x1)
+        x1 = e[5](h, residual=res)
+        n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
+        h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, _seed() if p2 > 0 else 0)
+        return e2[5](h, residual=res)
 
 
 class temporalEncoder(nn.Module):

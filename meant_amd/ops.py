@@ -83,18 +83,34 @@ weights = _WeightCache()
 
 
 # ---------------------------------------------------------------------------------------------
+def _rmsnorm_fwd_raw(x, scale, eps, drop_p, seed):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    rinv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    sc = _c(scale.detach().float())
+    check(lib.meant_rmsnorm_fwd(_p(x), _p(sc), _p(y), _p(rinv), rows, d, eps, drop_p, seed, _dt(x), _stream()), "rmsnorm_fwd")
+    return y, sc, rinv
+
+
+def _rmsnorm_bwd_raw(dy, x, sc, rinv, eps, drop_p, seed, dres=None, gelu_pre=None):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dscale = torch.empty(d, device=x.device, dtype=torch.float32)
+    wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+    check(lib.meant_rmsnorm_bwd(_p(dy), _p(x), _p(sc), _p(rinv), _p(dx), _p(dscale), rows, d, eps, drop_p, seed, _p(dres), _p(gelu_pre),
+                                _dt(x), _p(ws), wsb, _stream()), "rmsnorm_bwd")
+    return dx, dscale
+
+
 class _RMSNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, eps, drop_p, seed):
         _need_gpu(x, scale)
         x = _c(x)
-        d = x.shape[-1]
-        rows = x.numel() // d
-        y = torch.empty_like(x)
-        rinv = torch.empty(rows, device=x.device, dtype=torch.float32)
-        sc = _c(scale.detach().float())
-        check(lib.meant_rmsnorm_fwd(_p(x), _p(sc), _p(y), _p(rinv), rows, d, eps, drop_p, seed, _dt(x), _stream()),
-              "rmsnorm_fwd")
+        y, sc, rinv = _rmsnorm_fwd_raw(x, scale, eps, drop_p, seed)
         ctx.save_for_backward(x, sc, rinv)
         ctx.args = (eps, drop_p, seed)
         return y
@@ -102,21 +118,95 @@ class _RMSNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, sc, rinv = ctx.saved_tensors
-        eps, drop_p, seed = ctx.args
-        dy = _c(dy)
-        d = x.shape[-1]
-        rows = x.numel() // d
-        dx = torch.empty_like(x)
-        dscale = torch.empty(d, device=x.device, dtype=torch.float32)
-        wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
-        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
-        check(lib.meant_rmsnorm_bwd(_p(dy), _p(x), _p(sc), _p(rinv), _p(dx), _p(dscale), rows, d, eps, drop_p, seed,
-                                    _dt(x), _p(ws), wsb, _stream()), "rmsnorm_bwd")
+        dx, dscale = _rmsnorm_bwd_raw(_c(dy), x, sc, rinv, *ctx.args)
         return dx, dscale, None, None, None
 
 
 def rmsnorm(x, scale, eps=1e-8, drop_p=0.0, seed=0):
     return _RMSNorm.apply(x, scale, float(eps), float(drop_p), int(seed))
+
+
+class _RMSNormFork(torch.autograd.Function):
+    """(RMSNorm(x), x): the second output is x itself, to be used as the residual operand further down
+    (meant/meant.py:71,74).  Backward receives both gradients and adds the residual one inside the RMSNorm
+    backward kernel instead of in a separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, scale, eps):
+        _need_gpu(x, scale)
+        x = _c(x)
+        y, sc, rinv = _rmsnorm_fwd_raw(x, scale, eps, 0.0, 0)
+        ctx.save_for_backward(x, sc, rinv)
+        ctx.eps = eps
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, sc, rinv = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None
+        dres = _c(dres) if dres is not None else None
+        dx, dscale = _rmsnorm_bwd_raw(_c(dy), x, sc, rinv, ctx.eps, 0.0, 0, dres=dres)
+        return dx, dscale, None
+
+
+def rmsnorm_fork(x, scale, eps=1e-8):
+    return _RMSNormFork.apply(x, scale, float(eps))
+
+
+class _GeluRMSNorm(torch.autograd.Function):
+    """RMSNorm(gelu(pre)) given both the activation a = gelu(pre) (emitted by the GEMM epilogue) and pre: the
+    backward returns the gradient w.r.t. pre, the GELU derivative being applied inside the RMSNorm backward
+    kernel (meant/meant.py:64).  `a` is treated as an intermediate: its gradient slot is not used."""
+
+    @staticmethod
+    def forward(ctx, a, pre, scale, eps, drop_p, seed):
+        _need_gpu(a, pre, scale)
+        a = _c(a)
+        y, sc, rinv = _rmsnorm_fwd_raw(a, scale, eps, drop_p, seed)
+        ctx.save_for_backward(a, _c(pre), sc, rinv)
+        ctx.args = (eps, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, pre, sc, rinv = ctx.saved_tensors
+        dpre, dscale = _rmsnorm_bwd_raw(_c(dy), a, sc, rinv, *ctx.args, gelu_pre=pre)
+        return None, dpre, dscale, None, None, None
+
+
+class _LinearPre(torch.autograd.Function):
+    """Linear with GELU epilogue that hands out (gelu(h), h) with h = x W^T + b; gradients flow through h only
+    (the consumer, _GeluRMSNorm, chains the GELU derivative itself)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight)
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        w_c = weights.get((weight,), x.dtype, False)
+        bias_f = _c(bias.detach().float()) if bias is not None else None
+        y, pre = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_GELU, True)
+        ctx.weight, ctx.has_bias, ctx.in_shape = weight, bias is not None, shp
+        ctx.save_for_backward(x2)
+        N = weight.shape[0]
+        yv, pv = y.view(*shp[:-1], N), pre.view(*shp[:-1], N)
+        ctx.mark_non_differentiable(yv)
+        return yv, pv
+
+    @staticmethod
+    def backward(ctx, _dy_unused, dpre):
+        (x2,) = ctx.saved_tensors
+        N = ctx.weight.shape[0]
+        d2 = _c(dpre).view(-1, N)
+        dx, dw, db = _linear_bwd_raw(d2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias)
+        return (dx.view(ctx.in_shape) if dx is not None else None), dw, db
+
+
+def linear_gelu_rmsnorm(x, weight, bias, scale, eps=1e-8, drop_p=0.0, seed=0):
+    """RMSNorm(gelu(x W^T + b)) as two fused calls forward and two backward (meant/meant.py:64 / :107)."""
+    a, pre = _LinearPre.apply(x, weight, bias)
+    return _GeluRMSNorm.apply(a, pre, scale, float(eps), float(drop_p), int(seed))
 
 
 class _LayerNorm(torch.autograd.Function):
