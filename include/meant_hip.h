@@ -111,7 +111,9 @@ int meant_rotary_qk(void* qkv, int64_t T, int64_t S, int H, int Dh, int R, const
 /* ---- attention core -------- meant/attention.py:43-57, meant/xPosAttention.py:41-63
  * qkv: act [G*S, 3*H*Dh] packed (q | k | v column blocks, already rotated); o: act [G*S, H*Dh];
  * lse: float [G, H, S, 2] = (row max m, log sum_j exp(score_j - m)) of the scaled, masked scores --
- *      kept as a pair because the additive -1e9 padding term makes m ~ -1e9 on fully padded rows;
+ *      kept as a pair because the additive -1e9 padding term makes m ~ -1e9 on fully padded rows.  It is
+ *      opaque state handed from meant_attn_fwd to meant_attn_bwd of the SAME dtype (natural-log units in
+ *      the f32 tier, log2 units in the bf16 tier);
  * key_mask: float [G, S] of {0,1} or NULL (adds (1-mask)*-1e9 to the scores);
  * causal: scores[i,j] = -inf for j > i;  scale = 1/sqrt(H*Dh).
  * bf16: fused flash kernels; f32: materialised scores in `workspace`. */

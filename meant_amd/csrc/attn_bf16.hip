@@ -25,6 +25,8 @@
 #include "internal.h"
 #include <type_traits>
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -35,6 +37,7 @@ constexpr int DH = 64;
 constexpr int KV_TILE = 64;
 constexpr int TILE_B = KV_TILE * DH * 2;          // 8 KiB
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float PADL2 = 1e9f * 1.4426950408889634f;  // the reference's (1-mask) * -1e9 key-padding term, in log2 units
 
 __device__ __forceinline__ int swz(int r) { return ((r & 2) << 1) | ((r >> 2) & 3); }
 
@@ -128,9 +131,25 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], float m
 }
 
 // ------------------------------------------------------------------------------------------------
+// key-padding mask -> additive bias in log2 units, bias2[g][key] = (1 - mask) * -1e9 * log2e (0 for real keys,
+// -inf for the padding keys >= S of the last tile), and flags[g][tile] != 0 iff the tile needs the bias or the
+// tail treatment at all.  Padding is a suffix in practice, so most tiles take the bias-free path.
+__global__ __launch_bounds__(64) void attn_prep_mask_kernel(const float* __restrict__ km, float* __restrict__ bias2,
+                                                             int* __restrict__ flags, int S, int nt) {
+  const int g = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  const int key = t * KV_TILE + lane;
+  float b = 0.f;
+  if (key >= S) b = -INFINITY;
+  else if (km) b = fmaf(km[(int64_t)g * S + key], PADL2, -PADL2);
+  bias2[((int64_t)g * nt + t) * KV_TILE + lane] = b;
+  const int any = __any(b != 0.f);
+  if (lane == 0) flags[(int64_t)g * nt + t] = any;
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 struct FwdArgs {
-  const bf16* qkv; bf16* o; float* lse; const float* key_mask;
+  const bf16* qkv; bf16* o; float* lse; const float* bias2; const int* flags;
   int S, H; float scale; int causal;
 };
 
@@ -149,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
   const bf16* Kg = base + D;
   const bf16* Vg = base + 2 * D;
-  const float* km = a.key_mask ? a.key_mask + (int64_t)g * S : nullptr;
+  const int ntile = (S + KV_TILE - 1) / KV_TILE;
+  const float* b2g = a.bias2 + (int64_t)g * ntile * KV_TILE;     // this group's bias tiles
+  const int* flg = a.flags + (int64_t)g * ntile;
 
   // Q fragments (B operand): lane (query = lane&31, half) holds Q[q][16ks + 8*half .. +7]
   bf16x8 qf[4];
@@ -172,16 +193,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[b][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float c1 = a.scale * LOG2E;
 
   // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
   auto stage = [&](int t, int buf) {
     stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
     stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
-    if (km && wave == 0) {                           // the tile's 64 key-mask floats
-      int key = t * KV_TILE + lane;
-      key = key < S ? key : S - 1;
-      glds4(km + key, bias_s + buf * 64);
-    }
+    if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   const TrOff troff = make_troff(lane);
 
@@ -205,41 +223,62 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
         for (int ks = 0; ks < 4; ++ks)
           sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc[sb], 0, 0, 0);
       }
-      // scale, mask, running max
-      const bool tail = k0 + KV_TILE > S;
+      // softmax in the log2 domain: t = s * (scale*log2e) (+ bias), p = exp2(t - m).  Tiles that touch neither the
+      // diagonal, nor padding, nor the end of the sequence (most of them) take the mask-free path: one multiply and
+      // one max per score.  O and l are rescaled only on tiles where some lane's running max actually moves.
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);   // tile touches the diagonal for some query of this wave
-      float tmax = -INFINITY;
+      const bool special = diag || (flg[t] != 0);
+      float tmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (!special) {
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
+        for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int kl = 32 * sb + acc_row(e, lane);
-          float s = sacc[sb][e] * a.scale;
-          if (km) s += (1.0f - bias_s[buf * 64 + kl]) * -1e9f;
-          if ((diag && (k0 + kl > myq)) || (tail && (k0 + kl >= S))) s = -INFINITY;
-          sacc[sb][e] = s;
-          tmax = fmaxf(tmax, s);
-        }
+          for (int e = 0; e < 16; ++e) {
+            const float t = sacc[sb][e] * c1;
+            sacc[sb][e] = t;
+            tmx[e & 3] = fmaxf(tmx[e & 3], t);
+          }
+      } else {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int kl0 = 32 * sb + 8 * g4 + 4 * (lane >> 5);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + buf * 64 + kl0);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              float t = fmaf(sacc[sb][g4 * 4 + e4], c1, bv[e4]);
+              if (diag && (k0 + kl0 + e4 > myq)) t = -INFINITY;
+              sacc[sb][g4 * 4 + e4] = t;
+              tmx[e4] = fmaxf(tmx[e4], t);
+            }
+          }
+      }
+      float tmax = fmaxf(fmaxf(tmx[0], tmx[1]), fmaxf(tmx[2], tmx[3]));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
-      // m_new is finite for every real query: key 0 is never above the diagonal and biases are finite for key < S
-      const float alpha = __expf(m_run - m_new);
-      float psum = 0.f;
+      // m_run stays finite for every real query: key 0 is never above the diagonal and biases are finite for key < S
+      if (!__all(tmax <= m_run)) {
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
+      }
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float p = __expf(sacc[sb][e] - m_new);
+          const float p = __builtin_amdgcn_exp2f(sacc[sb][e] - m_run);
           sacc[sb][e] = p;
-          psum += p;
+          ps[e & 3] += p;
         }
+      float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
       psum += __shfl_xor(psum, 32, 64);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
+      l_run += psum;
       // O^T += V^T P^T
       const unsigned vaddr = lds_addr(Vt);
       auto pv = [&](auto SB) {
@@ -268,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   const float inv_l = 1.0f / l_run;
   if (lane < 32 && myq < S) {
     float* lp = a.lse + (((int64_t)g * H + h) * S + myq) * 2;
-    lp[0] = m_run;
-    lp[1] = __logf(l_run);
+    lp[0] = m_run;                                  // log2-domain statistics (tier-internal layout)
+    lp[1] = __log2f(l_run);
   }
   // 1/l differs per lane (query): scale per lane, then transpose through the wave's LDS patch
 #pragma unroll
@@ -283,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward, pass 1: dQ (and delta).  Same geometry as the forward.
 struct BwdArgs {
-  const bf16* qkv; const bf16* o; const bf16* dout; const float* lse; const float* key_mask; bf16* dqkv; float* delta;
+  const bf16* qkv; const bf16* o; const bf16* dout; const float* lse; const float* bias2; const int* flags; bf16* dqkv; float* delta;
   int S, H; float scale; int causal;
 };
 
@@ -300,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
   const bf16* Kg = base + D;
   const bf16* Vg = base + 2 * D;
-  const float* km = a.key_mask ? a.key_mask + (int64_t)g * S : nullptr;
+  const int ntile = (S + KV_TILE - 1) / KV_TILE;
+  const float* b2g = a.bias2 + (int64_t)g * ntile * KV_TILE;     // this group's bias tiles
+  const int* flg = a.flags + (int64_t)g * ntile;
   const int myq = q0 + (lane & 31);
   const int qrow = myq < S ? myq : S - 1;
 
@@ -320,13 +361,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     }
     delta += __shfl_xor(delta, 32, 64);
   }
-  float m_q, logl_q;
+  const float c1 = a.scale * LOG2E;
+  float m_q, logl_q;                                 // log2-domain (m, log2 l) written by the forward
   {
     const float* lp = a.lse + (((int64_t)g * H + h) * S + qrow) * 2;
     m_q = lp[0];
     logl_q = lp[1];
   }
   if (lane < 32 && myq < S) a.delta[((int64_t)g * H + h) * S + myq] = delta;
+  const float nml = -(m_q + logl_q);                 // used on tiles without padding, where |m| is small and the sum is exact enough
 
   int kend = S;
   if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
@@ -342,11 +385,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   auto stage = [&](int t, int buf) {
     stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
     stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
-    if (km && wave == 0) {                           // the tile's 64 key-mask floats
-      int key = t * KV_TILE + lane;
-      key = key < S ? key : S - 1;
-      glds4(km + key, bias_s + buf * 64);
-    }
+    if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   const TrOff troff = make_troff(lane);
 
@@ -360,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     if (active && q0 < S) {
       const char* Kt = smem + buf * 2 * TILE_B;
       const char* Vt = Kt + TILE_B;
-      const bool tail = k0 + KV_TILE > S;
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);
+      const bool special = diag || (flg[t] != 0);
       const unsigned kaddr = lds_addr(Kt);
       auto body = [&](auto SB) {
         constexpr int sb = decltype(SB)::value;
@@ -373,14 +412,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
           sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc, 0, 0, 0);
           dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vt, 32 * sb, ks, lane), dof[ks], dpacc, 0, 0, 0);
         }
+        if (!special) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int kl = 32 * sb + acc_row(e, lane);
-          float s = sacc[e] * a.scale;
-          if (km) s += (1.0f - bias_s[buf * 64 + kl]) * -1e9f;
-          float p = __expf((s - m_q) - logl_q);
-          if ((diag && (k0 + kl > myq)) || (tail && (k0 + kl >= S))) p = 0.f;
-          sacc[e] = p * (dpacc[e] - delta) * a.scale;          // dS^T
+          for (int e = 0; e < 16; ++e) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[e], c1, nml));      // exp2(t - m - log2 l), plain rows
+            sacc[e] = p * (dpacc[e] - delta);                                    // dS^T / scale
+          }
+        } else {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int kl0 = 32 * sb + 8 * g4 + 4 * (lane >> 5);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + buf * 64 + kl0);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const int e = g4 * 4 + e4;
+              const float t = fmaf(sacc[e], c1, bv[e4]);
+              float p = __builtin_amdgcn_exp2f((t - m_q) - logl_q);
+              if (diag && (k0 + kl0 + e4 > myq)) p = 0.f;
+              sacc[e] = p * (dpacc[e] - delta);
+            }
+          }
         }
         u32x2 lo[2][2], hi[2][2];
         tr_issue<32 * sb>(kaddr, troff, 0, lo[0][0], hi[0][0]);
@@ -402,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     __syncthreads();
   }
   if (q0 >= S) return;
-  store_transposed(dqacc, 1.0f, patches + wave * (32 * 144), a.dqkv + (int64_t)g * S * ld + h * DH, ld, q0, S, lane);
+  store_transposed(dqacc, a.scale, patches + wave * (32 * 144), a.dqkv + (int64_t)g * S * ld + h * DH, ld, q0, S, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,8 +486,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
       vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
     }
   }
-  float bkey = 0.f;
-  if (a.key_mask) bkey = (1.0f - a.key_mask[(int64_t)g * S + krow]) * -1e9f;
+  const float c1 = a.scale * LOG2E;
+  const int ntile = (S + KV_TILE - 1) / KV_TILE;
+  const float bkey = mykey < ntile * KV_TILE ? a.bias2[(int64_t)g * ntile * KV_TILE + mykey] : -INFINITY;   // key bias (log2 units; -inf past S)
 
   f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -493,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
         }
         const bool diag = a.causal && (qs0 < key0 + 31);
         const bool tail = qs0 + 32 > S;
+        const bool special = diag || tail;             // wave-uniform
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int ql = 32 * sq + 8 * g4 + 4 * (lane >> 5);          // 4 consecutive local query rows
@@ -504,12 +557,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             const int e = g4 * 4 + e4;
-            const int q = qt0 + ql + e4;
-            const float s = sacc[e] * a.scale + bkey;
-            float p = __expf((s - mv[e4]) - lv[e4]);
-            if ((diag && mykey > q) || (tail && q >= S)) p = 0.f;
+            const float t = fmaf(sacc[e], c1, bkey);
+            float p = __builtin_amdgcn_exp2f((t - mv[e4]) - lv[e4]);
+            if (special) {
+              const int q = qt0 + ql + e4;
+              if ((diag && mykey > q) || (tail && q >= S)) p = 0.f;
+            }
             sacc[e] = p;
-            dpacc[e] = p * (dpacc[e] - dv[e4]) * a.scale;
+            dpacc[e] = p * (dpacc[e] - dv[e4]);              // dS / scale
           }
         }
         u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
@@ -540,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
   }
   if (key0 >= S) return;
   char* patch = patches + wave * (32 * 144);
-  store_transposed(dkacc, 1.0f, patch, a.dqkv + (int64_t)g * S * ld + D + h * DH, ld, key0, S, lane);
+  store_transposed(dkacc, a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * DH, ld, key0, S, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   store_transposed(dvacc, 1.0f, patch, a.dqkv + (int64_t)g * S * ld + 2 * D + h * DH, ld, key0, S, lane);
@@ -553,10 +608,13 @@ constexpr int FWD_LDS = 4 * TILE_B + 2 * 64 * 4 + 4 * 32 * 144;
 
 // Head dims other than 64 (e.g. the reference's default 8 heads -> Dh = 96) take a widening detour:
 // bf16 -> f32 copies in the workspace, the fp32 attention core, f32 -> bf16.  Correct for any Dh, not fast.
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// workspace of the Dh=64 path: [delta: G*H*S floats | bias2: G*nt*64 floats | flags: G*nt ints]
+static size_t ws_delta_bytes(int64_t G, int64_t S, int H) { return align256((size_t)G * H * S * sizeof(float)); }
+static size_t ws_bias_bytes(int64_t G, int64_t S) { return align256((size_t)G * ceil_div(S, KV_TILE) * KV_TILE * sizeof(float)); }
+static size_t ws_flag_bytes(int64_t G, int64_t S) { return align256((size_t)G * ceil_div(S, KV_TILE) * sizeof(int)); }
 
 size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh) {
-  if (Dh == DH) return (size_t)G * H * S * sizeof(float);       // delta = rowsum(dO * O)
+  if (Dh == DH) return ws_delta_bytes(G, S, H) + ws_bias_bytes(G, S) + ws_flag_bytes(G, S);
   const size_t T = (size_t)G * S, D = (size_t)H * Dh;
   return 2 * align256(T * 3 * D * 4) + 2 * align256(T * D * 4) + attn_f32_ws(G, S, H, Dh);
 }
@@ -599,7 +657,13 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   int rc = attn_bf16_check("attn_fwd", G, S, H, Dh);
   if (rc) return rc;
   MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o), MEANT_ERR_ARG, "attn_fwd: 16-byte alignment");
-  FwdArgs a{qkv, o, lse, key_mask, (int)S, H, scale, causal};
+  MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn_fwd: workspace too small");
+  const int nt = (int)ceil_div(S, KV_TILE);
+  float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
+  int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
+  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt);
+  MEANT_LAUNCH_CHECK("attn_prep_mask");
+  FwdArgs a{qkv, o, lse, bias2, flags, (int)S, H, scale, causal};
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS); attr_set = true; }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
@@ -615,7 +679,12 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
   MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn_bwd: workspace too small");
   MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o) && meant_aligned16(dout) && meant_aligned16(dqkv), MEANT_ERR_ARG,
                 "attn_bwd: 16-byte alignment");
-  BwdArgs a{qkv, o, dout, lse, key_mask, dqkv, (float*)ws, (int)S, H, scale, causal};
+  const int nt = (int)ceil_div(S, KV_TILE);
+  float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
+  int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
+  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt);
+  MEANT_LAUNCH_CHECK("attn_prep_mask");
+  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, (int)S, H, scale, causal};
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
