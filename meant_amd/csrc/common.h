@@ -123,6 +123,12 @@ __device__ __forceinline__ void lds_wait_all() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+// counted form: returns when at most N of this wave's LDS operations are still outstanding (they retire in order)
+template <int N>
+__device__ __forceinline__ void lds_wait_upto() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ bf16x8 pack_tr(u32x2 lo, u32x2 hi) {
   u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bf16x8, v);

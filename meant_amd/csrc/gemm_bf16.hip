@@ -510,19 +510,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
       tn256_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, nxt + TN2_TILE, wave, lane);
     }
     const unsigned cbase = lds_addr(cur);
-    auto kstep = [&](auto KS) {
+    // fragment reads are software-pipelined one k-step ahead: while the MFMAs of k-step ks run, the 12 transposed
+    // reads of k-step ks+1 are in flight; the wait before the MFMAs is a counted lgkmcnt(12)
+    u32x2 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
+    auto issue = [&](auto KS) {
       constexpr int ks = decltype(KS)::value;
-      u32x2 alo[4], ahi[4], blo[2], bhi[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) tn256_frag_issue<ks>(cbase + aoff[i], alo[i], ahi[i]);
+      for (int i = 0; i < 4; ++i) tn256_frag_issue<ks>(cbase + aoff[i], alo[ks & 1][i], ahi[ks & 1][i]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tn256_frag_issue<ks>(cbase + TN2_TILE + boff[j], blo[j], bhi[j]);
-      lds_wait_all();
+      for (int j = 0; j < 2; ++j) tn256_frag_issue<ks>(cbase + TN2_TILE + boff[j], blo[ks & 1][j], bhi[ks & 1][j]);
+    };
+    auto compute = [&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
       bf16x8 af[4], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = pack_tr(alo[i], ahi[i]);
+      for (int i = 0; i < 4; ++i) af[i] = pack_tr(alo[ks & 1][i], ahi[ks & 1][i]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = pack_tr(blo[j], bhi[j]);
+      for (int j = 0; j < 2; ++j) bfr[j] = pack_tr(blo[ks & 1][j], bhi[ks & 1][j]);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -537,10 +541,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
-    kstep(std::integral_constant<int, 0>{});
-    kstep(std::integral_constant<int, 1>{});
-    kstep(std::integral_constant<int, 2>{});
-    kstep(std::integral_constant<int, 3>{});
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+    lds_wait_upto<12>();
+    compute(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 2>{});
+    lds_wait_upto<12>();
+    compute(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 3>{});
+    lds_wait_upto<12>();
+    compute(std::integral_constant<int, 2>{});
+    lds_wait_upto<0>();
+    compute(std::integral_constant<int, 3>{});
     __syncthreads();
   }
 #pragma unroll
@@ -624,8 +636,14 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
   }
   if (N % 256 == 0 && K % 256 == 0 && M >= 4096) {
     const int64_t ntn2 = N / 256, ntk2 = K / 256;
-    int64_t splits2 = ceil_div(512, ntn2 * ntk2);            // ~2 blocks per CU over the launch, 1 resident
-    const int64_t max2 = ceil_div(M, 512);
+    // one resident block per CU: size the launch to whole rounds of the CU count (a lone block in an extra
+    // round would cost a full round of time) -- one round when every block still gets >= 32 tiles of 64 rows
+    int ncu = meant_num_cus();
+    if (ncu <= 0) ncu = 256;
+    const int64_t tiles2 = ntn2 * ntk2;
+    int64_t splits2 = ncu / tiles2;
+    if (splits2 < 1) splits2 = 1;
+    const int64_t max2 = ceil_div(M, 32 * TN_BKM);
     if (splits2 > max2) splits2 = max2;
     int64_t rows2 = ceil_div(ceil_div(M, splits2), TN_BKM) * TN_BKM;
     splits2 = ceil_div(M, rows2);

@@ -8,6 +8,7 @@ fp32 (master weights), gradients of parameters are produced in fp32.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -56,7 +57,8 @@ class _WeightCache:
         key = (tuple(id(p) for p in params), dtype, transposed)
         ver = tuple((p._version, p.data_ptr()) for p in params)
         hit = self._store.get(key)
-        if hit is not None and hit[0] == ver:
+        # id() values are recycled once a parameter is freed: an entry is valid only for the very same objects
+        if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
             return hit[1]
         with torch.no_grad():
             w = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], dim=0)
@@ -72,7 +74,9 @@ class _WeightCache:
             else:
                 out = torch.empty((N, K), device=w.device, dtype=dtype)
                 check(lib.meant_cast(_p(w), sd, _p(out), dd, N * K, _stream()), "cast")
-        self._store[key] = (ver, out)
+        if len(self._store) > 4096:                    # entries of parameters that no longer exist
+            self._store = {k: v for k, v in self._store.items() if all(r() is not None for r in v[2])}
+        self._store[key] = (ver, out, tuple(weakref.ref(p) for p in params))
         return out
 
     def clear(self):
