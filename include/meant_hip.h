@@ -83,6 +83,12 @@ int meant_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
 int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                      int64_t ldr, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,
                      int epilogue, int dtype, void* stream);
+/* Fused q|k|v projection + rotary:  qkv[M, 3*H*Dh] = x[M,K] w[3*H*Dh, K]^T + bias, then the rotation of
+ * meant_rotary_qk on the q and k blocks (tables may be NULL: plain projection).  In the bf16 tier the rotation
+ * rides the GEMM epilogue (no extra pass over qkv).   meant/attention.py:36-40, meant/xPosAttention.py:37-39 */
+int meant_qkv_proj_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* qkv, int64_t M,
+                       int64_t K, int64_t S, int H, int Dh, int R, const float* qa, const float* qb,
+                       const float* ka, const float* kb, int dtype, void* stream);
 /* dx[M,K] = dy[M,N] w[N,K]   (wT is w transposed, [K,N], act dtype: see meant_transpose2d) */
 int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, int64_t M,
                         int64_t N, int64_t K, int dtype, void* stream);
@@ -121,10 +127,14 @@ size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
 int meant_attn_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H,
                    int Dh, float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
                    void* stream);
-/* dqkv: act [G*S, 3*H*Dh] (every element written); do_: act [G*S, H*Dh] */
+/* dqkv: act [G*S, 3*H*Dh] (every element written); do_: act [G*S, H*Dh].
+ * If the rotary tables qa,qb,ka,kb (float [S, R], as in meant_rotary_qk) are given, dq and dk are returned
+ * already pulled back through the rotation (the adjoint of meant_rotary_qk), i.e. dqkv is the gradient of
+ * the un-rotated projection; pass NULLs (and R = 0) for the gradient of the rotated buffer. */
 int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask,
-                   void* dqkv, int64_t G, int64_t S, int H, int Dh, float scale, int causal, int dtype,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   void* dqkv, int64_t G, int64_t S, int H, int Dh, float scale, int causal, const float* qa,
+                   const float* qb, const float* ka, const float* kb, int R, int dtype, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ---- temporal attention core ----------------------------- meant/temporal.py:44-56
  * q: act [B, H*Dh] (last lag step), kv: act [B*L, 2*H*Dh] packed (k | v); o: act [B, H*Dh];

@@ -46,6 +46,29 @@ extern "C" int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const
   return MEANT_ERR_ARG;
 }
 
+// Fused q|k|v projection + rotary (meant/attention.py:36-40, meant/xPosAttention.py:37-39): qkv[M, 3D] = x W^T + b with
+// the rotary / xPos rotation of the q and k blocks applied in the GEMM epilogue (bf16 tier) or by the rotary kernel.
+extern "C" int meant_qkv_proj_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* qkv, int64_t M, int64_t K,
+                                  int64_t S, int H, int Dh, int R, const float* qa, const float* qb, const float* ka,
+                                  const float* kb, int dtype, void* stream) {
+  MEANT_REQUIRE(x && w && qkv && H > 0 && Dh > 0 && S > 0 && M % S == 0, MEANT_ERR_ARG, "qkv_proj_fwd: bad argument");
+  const bool rot = qa != nullptr;
+  MEANT_REQUIRE(!rot || (qb && ka && kb && R > 0 && R % 2 == 0 && R <= Dh), MEANT_ERR_ARG, "qkv_proj_fwd: bad rotary tables");
+  const int64_t D = (int64_t)H * Dh, N = 3 * D;
+  const bool fused = rot && dtype == MEANT_BF16 && bf16_nt_ok(x, ldx, w, K, qkv, N, nullptr, 0, K) && Dh % 8 == 0 && R % 8 == 0;
+  if (fused) {
+    GemmBf16Args a{};
+    a.A = (const bf16*)x; a.lda = ldx; a.B = (const bf16*)w; a.ldb = K; a.C = (bf16*)qkv; a.ldc = N;
+    a.M = M; a.N = N; a.K = K; a.bias = bias;
+    a.rot_qa = qa; a.rot_qb = qb; a.rot_ka = ka; a.rot_kb = kb;
+    a.rot_S = (int)S; a.rot_D = (int)D; a.rot_Dh = Dh; a.rot_R = R;
+    return gemm_bf16_nt_launch(a, (hipStream_t)stream);
+  }
+  int rc = meant_linear_fwd(x, ldx, w, bias, nullptr, 0, qkv, N, nullptr, M, N, K, MEANT_EPI_NONE, dtype, stream);
+  if (rc || !rot) return rc;
+  return meant_rotary_qk(qkv, M, S, H, Dh, R, qa, qb, ka, kb, 0, dtype, stream);
+}
+
 extern "C" int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, int64_t M, int64_t N,
                                    int64_t K, int dtype, void* stream) {
   MEANT_REQUIRE(dy && wT && dx, MEANT_ERR_ARG, "linear_bwd_dx: null pointer");
@@ -133,17 +156,24 @@ extern "C" int meant_attn_fwd(const void* qkv, void* o, float* lse, const float*
 }
 
 extern "C" int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask, void* dqkv,
-                              int64_t G, int64_t S, int H, int Dh, float scale, int causal, int dtype, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              int64_t G, int64_t S, int H, int Dh, float scale, int causal, const float* qa, const float* qb,
+                              const float* ka, const float* kb, int R, int dtype, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  MEANT_REQUIRE((qa != nullptr) == (qb != nullptr) && (qa != nullptr) == (ka != nullptr) && (qa != nullptr) == (kb != nullptr), MEANT_ERR_ARG,
+                "attn_bwd: rotary tables must be given all or none");
+  const RotTables rot{qa, qb, ka, kb, R};
   MEANT_REQUIRE(qkv && o && do_ && lse && dqkv, MEANT_ERR_ARG, "attn_bwd: null pointer");
   int rc = attn_check("attn_bwd", G, S, H, Dh);
   if (rc) return rc;
-  if (dtype == MEANT_F32)
-    return attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)do_, lse, key_mask, (float*)dqkv, G, S, H, Dh, scale, causal,
-                        workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == MEANT_F32) {
+    rc = attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)do_, lse, key_mask, (float*)dqkv, G, S, H, Dh, scale, causal,
+                      workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc || !qa) return rc;
+    return meant_rotary_qk(dqkv, G * S, S, H, Dh, R, qa, qb, ka, kb, 1, MEANT_F32, stream);
+  }
   if (dtype == MEANT_BF16)
     return attn_bf16_bwd((const bf16*)qkv, (const bf16*)o, (const bf16*)do_, lse, key_mask, (bf16*)dqkv, G, S, H, Dh, scale, causal,
-                         workspace, workspace_bytes, (hipStream_t)stream);
+                         rot, workspace, workspace_bytes, (hipStream_t)stream);
   meant_set_error("attn_bwd: unknown dtype %d", dtype);
   return MEANT_ERR_ARG;
 }

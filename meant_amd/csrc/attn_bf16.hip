@@ -130,6 +130,31 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], float m
   }
 }
 
+// adjoint of the rotary map on a transposed gradient tile, in registers and fp32 (so the result is rounded once):
+// acc[b][e] holds d/d(rotated)[token = this lane's][dh = 32b + acc_row(e)]; pairs (2j, 2j+1) sit in adjacent
+// registers.  d t[2j] = A[2j] d[2j] + B[2j+1] d[2j+1] ;  d t[2j+1] = A[2j+1] d[2j+1] - B[2j] d[2j]  for dh < R.
+__device__ __forceinline__ void rotary_adjoint_regs(f32x16 (&acc)[2], const float* __restrict__ A, const float* __restrict__ B, int R,
+                                                    int pos, int lane) {
+  const float* Ar = A + (int64_t)pos * R;
+  const float* Br = B + (int64_t)pos * R;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dh = 32 * b + 8 * g4 + 4 * (lane >> 5);
+      if (dh < R) {                                   // R % 8 == 0 and dh % 4 == 0: the 4 lanes are in or out together
+        const f32x4 av = *reinterpret_cast<const f32x4*>(Ar + dh);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(Br + dh);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const float d0 = acc[b][g4 * 4 + e], d1 = acc[b][g4 * 4 + e + 1];
+          acc[b][g4 * 4 + e] = av[e] * d0 + bv[e + 1] * d1;
+          acc[b][g4 * 4 + e + 1] = av[e + 1] * d1 - bv[e] * d0;
+        }
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // key-padding mask -> additive bias in log2 units, bias2[g][key] = (1 - mask) * -1e9 * log2e (0 for real keys,
 // -inf for the padding keys >= S of the last tile), and flags[g][tile] != 0 iff the tile needs the bias or the
@@ -324,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 struct BwdArgs {
   const bf16* qkv; const bf16* o; const bf16* dout; const float* lse; const float* bias2; const int* flags; bf16* dqkv; float* delta;
   int S, H; float scale; int causal;
+  RotTables rot;                                     // adjoint rotary on dq / dk when rot.qa != null
 };
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
@@ -453,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     __syncthreads();
   }
   if (q0 >= S) return;
+  if (a.rot.qa) rotary_adjoint_regs(dqacc, a.rot.qa, a.rot.qb, a.rot.R, qrow, lane);
   store_transposed(dqacc, a.scale, patches + wave * (32 * 144), a.dqkv + (int64_t)g * S * ld + h * DH, ld, q0, S, lane);
 }
 
@@ -594,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     __syncthreads();
   }
   if (key0 >= S) return;
+  if (a.rot.ka) rotary_adjoint_regs(dkacc, a.rot.ka, a.rot.kb, a.rot.R, krow, lane);
   char* patch = patches + wave * (32 * 144);
   store_transposed(dkacc, a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * DH, ld, key0, S, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -672,8 +700,13 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
 }
 
 int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv, int64_t G,
-                  int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (Dh != DH) return attn_bf16_generic(true, qkv, o, dout, nullptr, const_cast<float*>(lse), key_mask, dqkv, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
+                  int64_t S, int H, int Dh, float scale, int causal, RotTables rot, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (Dh != DH) {
+    int rcg = attn_bf16_generic(true, qkv, o, dout, nullptr, const_cast<float*>(lse), key_mask, dqkv, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
+    if (rcg || !rot.qa) return rcg;
+    return meant_rotary_qk(dqkv, G * S, S, H, Dh, rot.R, rot.qa, rot.qb, rot.ka, rot.kb, 1, MEANT_BF16, stream);
+  }
+  MEANT_REQUIRE(!rot.qa || (rot.R % 8 == 0 && rot.R <= DH), MEANT_ERR_UNSUPPORTED, "attn_bwd: rotary dim must be a multiple of 8 and <= 64");
   int rc = attn_bf16_check("attn_bwd", G, S, H, Dh);
   if (rc) return rc;
   MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn_bwd: workspace too small");
@@ -684,7 +717,7 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
   hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt);
   MEANT_LAUNCH_CHECK("attn_prep_mask");
-  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, (int)S, H, scale, causal};
+  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, (int)S, H, scale, causal, rot};
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);

@@ -63,6 +63,66 @@ __device__ __forceinline__ void nt_stage(const bf16* __restrict__ g, int64_t ld,
   }
 }
 
+// one output row segment of 8 columns: v = acc + bias already; applies (optional) rotary, activation, residual,
+// rounds once and stores 16 bytes.  Rotary epilogue (fused QKV projection): columns are [q | k | v] blocks of
+// rot_D = H*Dh columns, a head is Dh columns, lanes c < R of every q/k head are rotated with the tables of the
+// token's position m mod S:  out[c] = t[c]*A[pos,c] + rot(t)[c]*B[pos,c]  (meant/rotary_embedding_torch.py:31-44).
+__device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, int64_t n, float (&v)[8], bool vec_ok) {
+  if (vec_ok) {
+    if (a.preact) {
+      bf16x8 p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p[e] = (bf16)v[e];
+      *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = p;
+    }
+    if (a.rot_qa) {
+      const int sec = (int)(n / a.rot_D);
+      const int c = (int)((n - (int64_t)sec * a.rot_D) % a.rot_Dh);
+      if (sec < 2 && c < a.rot_R) {
+        const int pos = (int)(m % a.rot_S);
+        const float* A = (sec ? a.rot_ka : a.rot_qa) + (int64_t)pos * a.rot_R + c;
+        const float* B = (sec ? a.rot_kb : a.rot_qb) + (int64_t)pos * a.rot_R + c;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(A), a1 = *reinterpret_cast<const f32x4*>(A + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(B), b1 = *reinterpret_cast<const f32x4*>(B + 4);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float t0 = v[e], t1 = v[e + 1];
+          const float A0 = e < 4 ? a0[e] : a1[e - 4], A1 = e < 4 ? a0[e + 1] : a1[e - 3];
+          const float B0 = e < 4 ? b0[e] : b1[e - 4], B1 = e < 4 ? b0[e + 1] : b1[e - 3];
+          v[e] = t0 * A0 - t1 * B0;
+          v[e + 1] = t1 * A1 + t0 * B1;
+        }
+      }
+    }
+    if (a.epilogue & MEANT_EPI_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (a.epilogue & MEANT_EPI_SIGMOID) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+    }
+    if (a.residual) {
+      const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
+  } else {
+    for (int e = 0; e < 8 && n + e < a.N; ++e) {
+      float x = v[e];
+      if (a.preact) a.preact[m * a.ldc + n + e] = (bf16)x;
+      if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf(x);
+      if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
+      if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
+      a.C[m * a.ldc + n + e] = (bf16)x;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Args a, int ntm, int ntn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -140,40 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Args a, in
     const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc + 4);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
-    if (vec_ok) {
-      if (a.preact) {
-        bf16x8 p;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) p[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = p;
-      }
-      if (a.epilogue & MEANT_EPI_GELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-      }
-      if (a.epilogue & MEANT_EPI_SIGMOID) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-      }
-      if (a.residual) {
-        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-      *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
-    } else {
-      for (int e = 0; e < 8 && n + e < a.N; ++e) {
-        float x = v[e];
-        if (a.preact) a.preact[m * a.ldc + n + e] = (bf16)x;
-        if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf(x);
-        if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
-        if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
-        a.C[m * a.ldc + n + e] = (bf16)x;
-      }
-    }
+    nt_store_row8(a, m, n, v, vec_ok);
   }
 }
 
@@ -287,40 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a,
       const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
-      if (vec_ok) {
-        if (a.preact) {
-          bf16x8 p;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) p[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = p;
-        }
-        if (a.epilogue & MEANT_EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        }
-        if (a.epilogue & MEANT_EPI_SIGMOID) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-        }
-        if (a.residual) {
-          const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
-      } else {
-        for (int e = 0; e < 8 && n + e < a.N; ++e) {
-          float x = v[e];
-          if (a.preact) a.preact[m * a.ldc + n + e] = (bf16)x;
-          if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf(x);
-          if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
-          if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
-          a.C[m * a.ldc + n + e] = (bf16)x;
-        }
-      }
+      nt_store_row8(a, m, n, v, vec_ok);
     }
   }
 }
@@ -579,6 +573,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
 
 int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_REQUIRE(a.A && a.B && a.C, MEANT_ERR_ARG, "gemm_bf16_nt: null pointer");
+  MEANT_REQUIRE(!a.rot_qa || (a.N == 3 * (int64_t)a.rot_D && a.rot_Dh % 8 == 0 && a.rot_R % 8 == 0 && (a.ldc & 7) == 0 && a.rot_D % a.rot_Dh == 0),
+                MEANT_ERR_ARG, "gemm_bf16_nt: rotary epilogue needs N = 3*H*Dh, Dh %% 8 == 0, rot_dim %% 8 == 0");
   MEANT_REQUIRE(a.K % BK == 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: K=%lld must be a multiple of %d (use the fp32 tier otherwise)", (long long)a.K, BK);
   MEANT_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0 && meant_aligned16(a.A) && meant_aligned16(a.B), MEANT_ERR_ARG,
                 "gemm_bf16_nt: operands must be 16-byte aligned with row strides that are multiples of 8");

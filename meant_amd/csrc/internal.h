@@ -31,6 +31,9 @@ struct GemmBf16Args {
   const bf16* residual; int64_t ldr;
   bf16* preact;             // ldc stride, or null
   int epilogue;
+  // optional rotary epilogue of the fused QKV projection (null rot_qa = off): tables float [S, R]
+  const float* rot_qa; const float* rot_qb; const float* rot_ka; const float* rot_kb;
+  int rot_S, rot_D, rot_Dh, rot_R;
 };
 int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream);
 // dW[N,K] (float, +=) = dY[M,N]^T X[M,K], reduction over the token axis M; dbias[N] += colsum(dY)
@@ -48,6 +51,9 @@ int attn_f32_bwd(const float* qkv, const float* o, const float* dout, const floa
 size_t attn_f32_ws(int64_t G, int64_t S, int H, int Dh);
 int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
                   float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+// rot: (qa, qb, ka, kb) float [S, R] or all-null: when given, the adjoint of the rotary map is applied to dq and dk
+struct RotTables { const float* qa; const float* qb; const float* ka; const float* kb; int R; };
 int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv,
-                  int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+                  int64_t G, int64_t S, int H, int Dh, float scale, int causal, RotTables rot, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
 size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh);

@@ -335,13 +335,12 @@ class _QKVAttention(torch.autograd.Function):
         x2 = _c(x).view(G * S, d)
         w_c = weights.get((wq, wk, wv), x.dtype, False)                      # [3D, d]
         bias_f = torch.cat([bq.detach(), bk.detach(), bv.detach()]).float().contiguous()
-        qkv, _ = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_NONE, False)      # [G*S, 3D]
         dt = _dt(x)
-        if tables is not None:
-            qa, qb, ka, kb = tables
-            R = qa.shape[1]
-            check(lib.meant_rotary_qk(_p(qkv), G * S, S, num_heads, Dh, R, _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()),
-                  "rotary_qk")
+        qa, qb, ka, kb = tables if tables is not None else (None, None, None, None)
+        R = qa.shape[1] if qa is not None else 0
+        qkv = torch.empty((G * S, 3 * D), device=x.device, dtype=x.dtype)
+        check(lib.meant_qkv_proj_fwd(_p(x2), x2.stride(0), _p(w_c), _p(bias_f), _p(qkv), G * S, d, S, num_heads, Dh, R,
+                                     _p(qa), _p(qb), _p(ka), _p(kb), dt, _stream()), "qkv_proj_fwd")
         o = torch.empty((G * S, D), device=x.device, dtype=x.dtype)
         lse = torch.empty((G, num_heads, S, 2), device=x.device, dtype=torch.float32)
         km = _c(key_mask.float()) if key_mask is not None else None
@@ -365,13 +364,11 @@ class _QKVAttention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         wsb = lib.meant_attn_ws(G, S, H, Dh, dt)
         ws = torch.empty(max(wsb, 16), device=do2.device, dtype=torch.uint8)
-        check(lib.meant_attn_bwd(_p(qkv), _p(o), _p(do2), _p(lse), _p(km), _p(dqkv), G, S, H, Dh, scale, causal, dt, _p(ws), wsb,
-                                 _stream()), "attn_bwd")
+        qa, qb, ka, kb = ctx.tables if ctx.tables is not None else (None, None, None, None)
+        R = qa.shape[1] if qa is not None else 0
+        check(lib.meant_attn_bwd(_p(qkv), _p(o), _p(do2), _p(lse), _p(km), _p(dqkv), G, S, H, Dh, scale, causal,
+                                 _p(qa), _p(qb), _p(ka), _p(kb), R, dt, _p(ws), wsb, _stream()), "attn_bwd")
         del ws
-        if ctx.tables is not None:
-            qa, qb, ka, kb = ctx.tables
-            check(lib.meant_rotary_qk(_p(dqkv), G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 1, dt, _stream()),
-                  "rotary_qk(T)")
         dx, dw, db = _linear_bwd_raw(dqkv, x2, ctx.params, ctx.needs_input_grad[0], True)
         dwq, dwk, dwv = dw[:D], dw[D:2 * D], dw[2 * D:]
         dbq, dbk, dbv = db[:D], db[D:2 * D], db[2 * D:]

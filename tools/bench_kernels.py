@@ -91,7 +91,7 @@ def bench_attn():
         fl = 4 * G * H * S * S * Dh
         print(f"  fwd G={G} S={S} causal={causal}: {t*1e3:7.3f} ms  {fl/t/1e12:6.1f} TFLOP/s (full-square count)  {4*G*S*D*2/t/1e9:6.0f} GB/s")
         do = torch.randn_like(o); dqkv = torch.empty_like(qkv)
-        f = lambda: check(lib.meant_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), mask.data_ptr() if mask is not None else None, dqkv.data_ptr(), G, S, H, Dh, scale, causal, BF16, ws.data_ptr(), wsb, st()))
+        f = lambda: check(lib.meant_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), mask.data_ptr() if mask is not None else None, dqkv.data_ptr(), G, S, H, Dh, scale, causal, None, None, None, None, 0, BF16, ws.data_ptr(), wsb, st()))
         t = timeit(f)
         print(f"  bwd G={G} S={S} causal={causal}: {t*1e3:7.3f} ms  {2.5*fl/t/1e12:6.1f} TFLOP/s (full-square count)")
 
