@@ -181,6 +181,10 @@ int meant_embedding_fwd(const float* table, const int64_t* ids, void* out, int64
                         void* stream);
 int meant_embedding_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t n, int64_t d, int64_t V, int dtype,
                         void* stream);
+/* same, over ids sorted by the caller: sorted_ids[j] ascending, order[j] = row of dout that carries it.  Rows of
+ * equal id are summed on chip before one atomic row add, so repeated tokens do not contend (d <= 1024). */
+int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorted_ids, const int64_t* order, float* dtable,
+                               int64_t n, int64_t d, int64_t V, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,35 @@ __global__ __launch_bounds__(EW_THREADS) void patchify_kernel(const TI* __restri
   }
 }
 
+// C == 4 fast path: a thread emits 8 consecutive outputs = 2 pixels x 4 channels (16 bytes for bf16) from four
+// 8-byte pixel-pair loads; consecutive threads walk p2, so both sides are coalesced per channel plane.
+template <typename TI, typename T>
+__global__ __launch_bounds__(EW_THREADS) void patchify_c4_kernel(const TI* __restrict__ img, T* __restrict__ out, int64_t G, int Hh,
+                                                                  int Ww, int p) {
+  const int nph = Hh / p, npw = Ww / p;
+  const int P = p * p * 4;
+  const int hp = p >> 1;                            // pixel pairs per patch row
+  const int64_t total = G * nph * npw * (int64_t)p * hp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / (p * hp);
+    int e = (int)(i - r * (p * hp));
+    const int pp = e % hp, p1 = e / hp;
+    const int pw = (int)(r % npw);
+    int64_t r2 = r / npw;
+    const int ph = (int)(r2 % nph);
+    const int64_t g = r2 / nph;
+    const int y = ph * p + p1, x = pw * p + 2 * pp;
+    Vec8<T> o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const TI* src = img + ((g * 4 + c) * Hh + y) * (int64_t)Ww + x;
+      o.set(c, to_f(src[0]));
+      o.set(4 + c, to_f(src[1]));
+    }
+    store8<T>(out + r * P + (p1 * p + 2 * pp) * 4, o);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K8 mean over the sequence axis.  block = (g, 256-column slab): 32 chunks x 8 row groups.
 template <typename T, typename TO>
@@ -314,6 +343,46 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* __restrict_
   }
 }
 
+// scatter-add of the embedding gradient over ids SORTED by the caller (order[j] = original row of the j-th smallest
+// id): one wave walks 32 consecutive sorted entries, sums rows of equal id in registers and issues one row of float
+// atomics per run instead of per token.  Duplicate ids (padding tokens, frequent words) no longer hammer one row.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const T* __restrict__ dout, const int64_t* __restrict__ sorted_ids,
+                                                                    const int64_t* __restrict__ order, float* __restrict__ dtable,
+                                                                    int64_t n, int d, int64_t V) {
+  constexpr int RUN = 32, MAXC = 16;                // d <= 64 * MAXC
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * RUN;
+  if (j0 >= n) return;
+  const int64_t j1 = j0 + RUN < n ? j0 + RUN : n;
+  float acc[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+  int64_t cur = sorted_ids[j0];
+  for (int64_t j = j0; j < j1; ++j) {
+    const int64_t id = sorted_ids[j];
+    if (id != cur) {
+      if (cur >= 0 && cur < V) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c * 64 + lane < d) atomicAdd(dtable + cur * d + c * 64 + lane, acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+      cur = id;
+    }
+    const T* src = dout + order[j] * d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c * 64 + lane < d) acc[c] += to_f(src[c * 64 + lane]);
+  }
+  if (cur >= 0 && cur < V) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c * 64 + lane < d) atomicAdd(dtable + cur * d + c * 64 + lane, acc[c]);
+  }
+}
+
 }  // namespace
 
 #define EW_REQ(c, ...) MEANT_REQUIRE(c, MEANT_ERR_ARG, __VA_ARGS__)
@@ -405,8 +474,17 @@ extern "C" int meant_rotary_qk(void* qkv, int64_t T_rows, int64_t S, int H, int 
 extern "C" int meant_patchify(const void* images, int images_dtype, void* patches, int64_t G, int C, int Hh, int Ww, int p, int dtype, void* stream) {
   EW_REQ(images && patches && G > 0 && C > 0 && p > 0 && Hh % p == 0 && Ww % p == 0, "patchify: bad argument");
   const int64_t total = G * C * (int64_t)Hh * Ww;
-  const dim3 grid(ew_blocks(total)), block(EW_THREADS);
   hipStream_t st = (hipStream_t)stream;
+  if (C == 4 && p % 2 == 0 && Ww % 2 == 0 && meant_aligned16(patches)) {
+    const dim3 grid4(ew_blocks(total / 8)), block4(EW_THREADS);
+    bool ok = true;
+    if (images_dtype == MEANT_F32 && dtype == MEANT_F32) hipLaunchKernelGGL((patchify_c4_kernel<float, float>), grid4, block4, 0, st, (const float*)images, (float*)patches, G, Hh, Ww, p);
+    else if (images_dtype == MEANT_F32 && dtype == MEANT_BF16) hipLaunchKernelGGL((patchify_c4_kernel<float, bf16>), grid4, block4, 0, st, (const float*)images, (bf16*)patches, G, Hh, Ww, p);
+    else if (images_dtype == MEANT_BF16 && dtype == MEANT_BF16) hipLaunchKernelGGL((patchify_c4_kernel<bf16, bf16>), grid4, block4, 0, st, (const bf16*)images, (bf16*)patches, G, Hh, Ww, p);
+    else ok = false;
+    if (ok) { MEANT_LAUNCH_CHECK("patchify_c4"); return MEANT_OK; }
+  }
+  const dim3 grid(ew_blocks(total)), block(EW_THREADS);
   if (images_dtype == MEANT_F32 && dtype == MEANT_F32) hipLaunchKernelGGL((patchify_kernel<float, float>), grid, block, 0, st, (const float*)images, (float*)patches, G, C, Hh, Ww, p);
   else if (images_dtype == MEANT_F32 && dtype == MEANT_BF16) hipLaunchKernelGGL((patchify_kernel<float, bf16>), grid, block, 0, st, (const float*)images, (bf16*)patches, G, C, Hh, Ww, p);
   else if (images_dtype == MEANT_BF16 && dtype == MEANT_BF16) hipLaunchKernelGGL((patchify_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)images, (bf16*)patches, G, C, Hh, Ww, p);
@@ -467,6 +545,18 @@ extern "C" int meant_embedding_fwd(const float* table, const int64_t* ids, void*
   MEANT_LAUNCH_CHECK("embedding_fwd");
   return MEANT_OK;
 }
+extern "C" int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorted_ids, const int64_t* order, float* dtable, int64_t n,
+                                          int64_t d, int64_t V, int dtype, void* stream) {
+  EW_REQ(dout && sorted_ids && order && dtable && n > 0 && d > 0 && V > 0, "embedding_bwd_sorted: bad argument");
+  MEANT_REQUIRE(d <= 1024, MEANT_ERR_UNSUPPORTED, "embedding_bwd_sorted: d=%lld > 1024", (long long)d);
+  const int64_t nb = ceil_div(n, 4 * 32);
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(embedding_bwd_sorted_kernel<T>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const T*)dout,
+                                    sorted_ids, order, dtable, n, (int)d, V));
+  MEANT_LAUNCH_CHECK("embedding_bwd_sorted");
+  return MEANT_OK;
+}
+
 extern "C" int meant_embedding_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t n, int64_t d, int64_t V, int dtype, void* stream) {
   EW_REQ(dout && ids && dtable && n > 0 && d > 0 && V > 0, "embedding_bwd: bad argument");
   int64_t nb = ceil_div(n, 4); if (nb > 8192) nb = 8192;

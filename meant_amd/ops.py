@@ -537,7 +537,14 @@ class _Embedding(torch.autograd.Function):
         V, d = ctx.meta
         dout = _c(dout)
         dtab = torch.zeros((V, d), device=dout.device, dtype=torch.float32)
-        check(lib.meant_embedding_bwd(_p(dout), _p(ids_c), _p(dtab), ids_c.numel(), d, V, _dt(dout), _stream()), "embedding_bwd")
+        n = ids_c.numel()
+        if d <= 1024 and n >= 4096:
+            # index preparation (a sort of the token ids) is host-side plumbing; the reduction itself is the HIP kernel
+            sorted_ids, order = torch.sort(ids_c.view(-1))
+            check(lib.meant_embedding_bwd_sorted(_p(dout), _p(sorted_ids), _p(order), _p(dtab), n, d, V, _dt(dout), _stream()),
+                  "embedding_bwd_sorted")
+        else:
+            check(lib.meant_embedding_bwd(_p(dout), _p(ids_c), _p(dtab), n, d, V, _dt(dout), _stream()), "embedding_bwd")
         return None, dtab, None
 
 

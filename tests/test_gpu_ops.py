@@ -311,6 +311,25 @@ def test_meanpool_patchify_embedding_rowvec(M, O, dev, dtype):
     assert_close(vh.grad, gy.to(dtype).float().sum(0, keepdim=True), 1e-5 if dtype == torch.float32 else 1e-2, "d temp_embedding")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_embedding_backward_sorted_path(M, dev, dtype):
+    """large token counts take the sorted scatter-add: heavy duplication (a padding-like hot id) must sum exactly"""
+    from meant_amd import ops
+    g = torch.Generator().manual_seed(3)
+    V, d, n = 300, 768, 3 * 2048
+    table = torch.randn(V, d, generator=g)
+    ids = torch.randint(0, V, (3, 2048), generator=g)
+    ids[0, :1500] = 7                                  # one id carries a quarter of all tokens
+    th = table.to(dev).requires_grad_()
+    e = ops.embedding(ids.to(dev), th, dtype)
+    ge = torch.randn(3, 2048, d, generator=g)
+    e.backward(ge.to(dev).to(dtype))
+    tr = table.clone().requires_grad_()
+    torch.nn.functional.embedding(ids, tr).backward(ge.to(dtype).float())
+    assert_grad_close(th.grad, tr.grad, 1e-5 if dtype == torch.float32 else 2e-3, "d embedding (sorted)")
+    assert th.grad[8:].abs().sum() > 0 and torch.equal(th.grad[V - 1:].cpu() == 0, tr.grad[V - 1:] == 0)
+
+
 def test_errors_are_loud(M, dev):
     from meant_amd import ops
     with pytest.raises(RuntimeError):
