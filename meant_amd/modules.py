@@ -30,6 +30,11 @@ from . import ops
 from ._lib import EPI_NONE, EPI_GELU, EPI_SIGMOID
 
 
+# Compose the encoder's Linear(d,d) with the q/k/v Linears that follow it without any nonlinearity
+# (meant/meant.py:60-61,102-103): same function and gradients, one per-token projection less.  Set to False to
+# run the two Linears separately, exactly as the reference's module list does.
+COMPOSE_PRE_LINEAR = True
+
 # ------------------------------------------------------------------------------------------
 # precision tier selection
 def resolve_compute_dtype(module: nn.Module, like: Optional[torch.Tensor]) -> torch.dtype:
@@ -156,10 +161,12 @@ class attention(nn.Module):
         self.v = Linear(self.dim, self.Dh * self.num_heads)
         self.k = Linear(self.dim, self.Dh * self.num_heads)
 
-    def core(self, x):
+    def core(self, x, pre=None):
+        """pre: an nn.Linear that the caller would have applied to x right before this module (composed into q/k/v)"""
         tables = self.pos_emb.tables(x.shape[1], x.device) if self.pos_emb is not None else None
+        prew = (pre.weight, pre.bias) if pre is not None else None
         return ops.qkv_attention(x, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,
-                                 tables, None, bool(self.mask), self.num_heads)
+                                 tables, None, bool(self.mask), self.num_heads, pre=prew)
 
     def forward(self, input):
         out = self.multi_mad(self.core(input))
@@ -185,10 +192,11 @@ class xPosAttention(nn.Module):
         self.v = Linear(self.dim, self.Dh * self.num_heads)
         self.k = Linear(self.dim, self.Dh * self.num_heads)
 
-    def core(self, x, attention_mask=None):
+    def core(self, x, attention_mask=None, pre=None):
         tables = self.xPos.tables(x.shape[1], x.device)
+        prew = (pre.weight, pre.bias) if pre is not None else None
         return ops.qkv_attention(x, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,
-                                 tables, attention_mask, bool(self.mask), self.num_heads)
+                                 tables, attention_mask, bool(self.mask), self.num_heads, pre=prew)
 
     def forward(self, input, attention_mask=None):
         if self.training and self.dropout.p > 0:
@@ -237,7 +245,11 @@ class visionEncoder(nn.Module):
     def forward(self, input):
         e, e2 = self.encode, self.encode2
         n, res = ops.rmsnorm_fork(input, e[0].scale, e[0].eps)      # residual gradient is folded into this norm's backward
-        h = e[3](e[2](e[1](n)))
+        if COMPOSE_PRE_LINEAR and e[1].bias is not None:
+            h = e[2].multi_mad(e[2].core(n, pre=e[1]))               # Linear(d,d) composed into the q/k/v projections
+        else:
+            h = e[2](e[1](n))
+        h = e[3](h)
         x1 = e[4](h, residual=res)
         n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
         h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
@@ -261,7 +273,10 @@ class languageEncoder(nn.Module):
         p1 = e[4].p if self.training else 0.0
         p2 = e2[4].p if self.training else 0.0
         n, res = ops.rmsnorm_fork(input, e[0].scale, e[0].eps)
-        h = e[2](e[1](n), attention_mask)
+        if COMPOSE_PRE_LINEAR and e[1].bias is not None:
+            h = e[2].multi_mad(e[2].core(n, attention_mask, pre=e[1]))
+        else:
+            h = e[2](e[1](n), attention_mask)
         h = e[3](h, drop_p=p1, seed=_seed() if p1 > 0 else 0)
         x1 = e[5](h, residual=res)
         n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)

@@ -319,22 +319,74 @@ def linear(x, weight, bias=None, residual=None, epilogue=EPI_NONE):
 
 
 # ---------------------------------------------------------------------------------------------
-class _QKVAttention(torch.autograd.Function):
-    """Fused q/k/v projection + rotary + attention core of meant/attention.py:35-57 and
-    meant/xPosAttention.py:35-63 (up to, not including, multi_mad).
+def _gemm_f32(A, B, C, M, N, K, sA, sB, sC, alpha=1.0, accumulate=False):
+    """C[m,n] (+)= alpha * sum_k A(m,k) B(k,n) on fp32 tensors with explicit (row, col) element strides"""
+    import ctypes
+    arr = ctypes.c_int64 * 4
+    check(lib.meant_gemm_f32_strided(_p(A), _p(B), _p(C), M, N, K, 1, 1, arr(0, 0, *sA), arr(0, 0, *sB), arr(0, 0, *sC),
+                                     float(alpha), int(accumulate), _stream()), "gemm_f32_strided")
 
-    wq, wk, wv are the parameters the reference calls q, v, k respectively (the k/v naming
-    swap is resolved by the caller).  tables = (qa, qb, ka, kb) float [S, R] or None."""
+
+class _ComposeLinear(torch.autograd.Function):
+    """Two consecutive Linears with nothing between them -- the encoder's Linear(d,d) feeding the q/k/v Linears
+    (meant/meant.py:60-61 -> meant/attention.py:36-37, meant/meant.py:102-103 -> meant/xPosAttention.py:37-38) --
+    are one affine map:  (x W1^T + b1) Wqkv^T + bqkv = x (Wqkv W1)^T + (Wqkv b1 + bqkv).
+    This function forms the composed weight and bias (fp32, a 3D x d x d product on the weights only) and, in
+    backward, maps their gradients back to all four parameter tensors, so the per-token projection runs once
+    instead of twice in forward and in both backward GEMMs.  Same function, same parameters, same gradients."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads):
-        _need_gpu(x, wq)
+    def forward(ctx, w1, b1, wqkv, bqkv):
+        _need_gpu(w1, wqkv)
+        w1c, wqc = _c(w1.detach().float()), _c(wqkv.detach().float())
+        b1c, bqc = _c(b1.detach().float()), _c(bqkv.detach().float())
+        N3, dj = wqc.shape
+        dk = w1c.shape[1]
+        wc = torch.empty((N3, dk), device=w1.device, dtype=torch.float32)
+        _gemm_f32(wqc, w1c, wc, N3, dk, dj, (dj, 1), (dk, 1), (dk, 1))
+        bc = bqc.clone()
+        _gemm_f32(wqc, b1c, bc, N3, 1, dj, (dj, 1), (1, 0), (1, 1), accumulate=True)
+        ctx.save_for_backward(w1c, b1c, wqc)
+        return wc, bc
+
+    @staticmethod
+    def backward(ctx, dwc, dbc):
+        w1c, b1c, wqc = ctx.saved_tensors
+        N3, dj = wqc.shape
+        dk = w1c.shape[1]
+        dwc, dbc = _c(dwc.float()), _c(dbc.float())
+        dwq = torch.empty_like(wqc)                                         # dWqkv = dWc W1^T + dbc (x) b1
+        _gemm_f32(dwc, w1c, dwq, N3, dj, dk, (dk, 1), (1, dk), (dj, 1))
+        _gemm_f32(dbc, b1c, dwq, N3, dj, 1, (1, 0), (0, 1), (dj, 1), accumulate=True)
+        dw1 = torch.empty_like(w1c)                                         # dW1 = Wqkv^T dWc
+        _gemm_f32(wqc, dwc, dw1, dj, dk, N3, (1, dj), (dk, 1), (dk, 1))
+        db1 = torch.empty_like(b1c)                                         # db1 = Wqkv^T dbc
+        _gemm_f32(wqc, dbc, db1, dj, 1, N3, (1, dj), (1, 0), (1, 1))
+        return dw1, db1, dwq, dbc
+
+
+def compose_linear(w1, b1, wqkv, bqkv):
+    return _ComposeLinear.apply(w1, b1, wqkv, bqkv)
+
+
+class _QKVAttention(torch.autograd.Function):
+    """Fused q|k|v projection + rotary + attention core of meant/attention.py:35-57 and
+    meant/xPosAttention.py:35-63 (up to, not including, multi_mad).
+
+    wqkv [3D, d] / bqkv [3D] hold the projections in the order (query, KEY, VALUE) -- i.e. the reference's
+    parameters (q, v, k): the k/v naming swap is resolved by the caller.  They may be the composed
+    weight of _ComposeLinear.  tables = (qa, qb, ka, kb) float [S, R] or None."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, tables, key_mask, causal, num_heads):
+        _need_gpu(x, wqkv)
         G, S, d = x.shape
-        D = wq.shape[0]
+        D = wqkv.shape[0] // 3
         Dh = D // num_heads
         x2 = _c(x).view(G * S, d)
-        w_c = weights.get((wq, wk, wv), x.dtype, False)                      # [3D, d]
-        bias_f = torch.cat([bq.detach(), bk.detach(), bv.detach()]).float().contiguous()
+        w_f = _c(wqkv.detach().float())
+        w_c = cast(w_f, x.dtype)                                              # [3D, d] in the compute dtype
+        bias_f = _c(bqkv.detach().float())
         dt = _dt(x)
         qa, qb, ka, kb = tables if tables is not None else (None, None, None, None)
         R = qa.shape[1] if qa is not None else 0
@@ -349,15 +401,14 @@ class _QKVAttention(torch.autograd.Function):
         ws = torch.empty(max(wsb, 16), device=x.device, dtype=torch.uint8)
         check(lib.meant_attn_fwd(_p(qkv), _p(o), _p(lse), _p(km), G, S, num_heads, Dh, scale, int(causal), dt, _p(ws), wsb,
                                  _stream()), "attn_fwd")
-        ctx.save_for_backward(x2, qkv, o, lse, km)
-        ctx.params = (wq, wk, wv)
+        ctx.save_for_backward(x2, qkv, o, lse, km, w_f)
         ctx.tables = tables
         ctx.meta = (G, S, d, D, Dh, num_heads, scale, int(causal))
         return o.view(G, S, D)
 
     @staticmethod
     def backward(ctx, do):
-        x2, qkv, o, lse, km = ctx.saved_tensors
+        x2, qkv, o, lse, km, w_f = ctx.saved_tensors
         G, S, d, D, Dh, H, scale, causal = ctx.meta
         do2 = _c(do).view(G * S, D)
         dt = _dt(do2)
@@ -369,14 +420,26 @@ class _QKVAttention(torch.autograd.Function):
         check(lib.meant_attn_bwd(_p(qkv), _p(o), _p(do2), _p(lse), _p(km), _p(dqkv), G, S, H, Dh, scale, causal,
                                  _p(qa), _p(qb), _p(ka), _p(kb), R, dt, _p(ws), wsb, _stream()), "attn_bwd")
         del ws
-        dx, dw, db = _linear_bwd_raw(dqkv, x2, ctx.params, ctx.needs_input_grad[0], True)
-        dwq, dwk, dwv = dw[:D], dw[D:2 * D], dw[2 * D:]
-        dbq, dbk, dbv = db[:D], db[D:2 * D], db[2 * D:]
-        return (dx.view(G, S, d) if dx is not None else None), dwq, dbq, dwk, dbk, dwv, dbv, None, None, None, None
+        M, N, K = G * S, 3 * D, d
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wT = torch.empty((K, N), device=do2.device, dtype=do2.dtype)
+            check(lib.meant_transpose2d(_p(w_f), F32, _p(wT), dt, N, K, _stream()), "transpose2d")
+            dx = torch.empty((M, K), device=do2.device, dtype=do2.dtype)
+            check(lib.meant_linear_bwd_dx(_p(dqkv), N, _p(wT), _p(dx), K, M, N, K, dt, _stream()), "linear_bwd_dx")
+        dw = torch.zeros((N, K), device=do2.device, dtype=torch.float32)
+        db = torch.zeros(N, device=do2.device, dtype=torch.float32)
+        check(lib.meant_linear_bwd_dw(_p(dqkv), N, _p(x2), x2.stride(0), _p(dw), _p(db), M, N, K, dt, _stream()), "linear_bwd_dw")
+        return (dx.view(G, S, d) if dx is not None else None), dw, db, None, None, None, None
 
 
-def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads):
-    return _QKVAttention.apply(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads)
+def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads, pre=None):
+    """pre = (W1, b1) of a Linear applied to x immediately before the projections (composed into them)."""
+    wqkv = torch.cat([wq, wk, wv], dim=0)
+    bqkv = torch.cat([bq, bk, bv], dim=0)
+    if pre is not None:
+        wqkv, bqkv = compose_linear(pre[0], pre[1], wqkv, bqkv)
+    return _QKVAttention.apply(x, wqkv, bqkv, tables, key_mask, causal, num_heads)
 
 
 # ---------------------------------------------------------------------------------------------
