@@ -186,6 +186,21 @@ int meant_embedding_bwd(const void* dout, const int64_t* ids, float* dtable, int
 int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorted_ids, const int64_t* order, float* dtable,
                                int64_t n, int64_t d, int64_t V, int dtype, void* stream);
 
+/* ---- train-step tail ------------------------------------------- in_loop_train.py:232-238,547-548
+ * CrossEntropyLoss (mean) applied to the model's probabilities [B, C] as the reference does: loss_accum[0] +=
+ * loss (caller zeroes it), dprobs (optional) receives d loss / d probs. */
+int meant_ce_probs(const float* probs, const int64_t* target, float* loss_accum, float* dprobs, int64_t B, int C,
+                   void* stream);
+/* out_accum[0] += sum(x^2) over a flat float buffer (global gradient norm; caller zeroes the scalar) */
+int meant_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream);
+/* One AdamW step (torch.optim.AdamW semantics, `step` >= 1 for the bias corrections) over flat float buffers.
+ * Gradients are read as g * grad_scale * clip with clip = min(1, max_norm / (sqrt(*sumsq) * |grad_scale| + 1e-6))
+ * (torch.nn.utils.clip_grad_norm_), taken from the device scalar sumsq: no host round trip.  sumsq NULL or
+ * max_norm <= 0 disables clipping. */
+int meant_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, const float* sumsq, float max_norm,
+                    float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

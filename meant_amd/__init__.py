@@ -12,4 +12,6 @@ from .modules import (  # noqa: F401
     meant, meant_vision, meant_tweet, meant_vqa,
 )
 
+from . import parallel, train  # noqa: F401,E402
+
 __version__ = "0.1.0"

@@ -1,0 +1,115 @@
+// Train-step tail of the MEANT path (in_loop_train.py:232-238, 547-548): cross-entropy on the model's
+// probabilities, global-norm gradient clipping and AdamW, as fused kernels over the FLAT fp32 buckets
+// that the data-parallel reducer already keeps (meant_amd/parallel.py): one launch per bucket instead
+// of PyTorch's per-tensor foreach chains, the clip coefficient applied on the fly from a device scalar
+// (no host synchronisation anywhere in the step).  HBM-bound: 4 reads + 3 writes of 4 bytes per parameter.
+#include "common.h"
+
+namespace {
+
+// out[0] += sum(x^2): block-level tree, one float atomic per block
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t nv = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  for (int64_t i = (nv << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.AdamW semantics (decoupled weight decay, bias-corrected moments):
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// with g pre-multiplied by the clip coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) (clip_grad_norm_).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                     float wd, float bc1, float bc2, const float* __restrict__ sumsq,
+                                                     float max_norm, float grad_scale) {
+  float clip = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    const float norm = sqrtf(*sumsq) * fabsf(grad_scale);
+    const float c = max_norm / (norm + 1e-6f);
+    clip *= c < 1.f ? c : 1.f;
+  }
+  const float step = lr / bc1, isb2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  const int64_t nv = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4), mv = *reinterpret_cast<f32x4*>(m + i * 4), vv = *reinterpret_cast<f32x4*>(v + i * 4);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gv[k] * clip;
+      mv[k] = b1 * mv[k] + (1.f - b1) * gk;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+      pv[k] = pv[k] * decay - step * mv[k] / (sqrtf(vv[k]) * isb2 + eps);
+    }
+    *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+    *reinterpret_cast<f32x4*>(m + i * 4) = mv;
+    *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+  }
+  for (int64_t i = (nv << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gk = g[i] * clip;
+    const float mk = b1 * m[i] + (1.f - b1) * gk, vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    m[i] = mk; v[i] = vk;
+    p[i] = p[i] * decay - step * mk / (sqrtf(vk) * isb2 + eps);
+  }
+}
+
+// CrossEntropyLoss(reduction='mean') applied to probabilities (the reference feeds the Sigmoid output to it,
+// in_loop_train.py:232): loss = mean_b( logsumexp(x_b) - x_b[t_b] ), dx = (softmax(x_b) - onehot) / B.  One thread per row.
+__global__ void ce_probs_kernel(const float* __restrict__ x, const int64_t* __restrict__ target, float* __restrict__ loss,
+                                float* __restrict__ dx, int64_t B, int C) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float l = 0.f;
+  if (b < B) {
+    const float* r = x + b * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, r[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(r[c] - mx);
+    const float lse = mx + logf(s);
+    const int64_t t = target[b];
+    l = (lse - r[t]) / (float)B;
+    if (dx) for (int c = 0; c < C; ++c) dx[b * C + c] = (expf(r[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
+  }
+  l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+}
+
+}  // namespace
+
+extern "C" int meant_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream) {
+  MEANT_REQUIRE(x && out_accum && n >= 0 && meant_aligned16(x), MEANT_ERR_ARG, "sumsq_f32: bad argument");
+  if (n == 0) return MEANT_OK;
+  int64_t nb = ceil_div(n, 256 * 16);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, n, out_accum);
+  MEANT_LAUNCH_CHECK("sumsq_f32");
+  return MEANT_OK;
+}
+
+extern "C" int meant_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, const float* sumsq, float max_norm, float grad_scale, void* stream) {
+  MEANT_REQUIRE(p && g && m && v && n >= 0 && step >= 1, MEANT_ERR_ARG, "adamw_f32: bad argument");
+  MEANT_REQUIRE(meant_aligned16(p) && meant_aligned16(g) && meant_aligned16(m) && meant_aligned16(v), MEANT_ERR_ARG, "adamw_f32: 16-byte alignment");
+  if (n == 0) return MEANT_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  int64_t nb = ceil_div(n, 256 * 4);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     bc1, bc2, sumsq, max_norm, grad_scale);
+  MEANT_LAUNCH_CHECK("adamw_f32");
+  return MEANT_OK;
+}
+
+extern "C" int meant_ce_probs(const float* probs, const int64_t* target, float* loss_accum, float* dprobs, int64_t B, int C, void* stream) {
+  MEANT_REQUIRE(probs && target && loss_accum && B > 0 && C > 0, MEANT_ERR_ARG, "ce_probs: bad argument");
+  hipLaunchKernelGGL(ce_probs_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, (hipStream_t)stream, probs, target, loss_accum, dprobs, B, C);
+  MEANT_LAUNCH_CHECK("ce_probs");
+  return MEANT_OK;
+}

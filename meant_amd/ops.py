@@ -51,11 +51,17 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 class _WeightCache:
     def __init__(self):
         self._store = {}
+        self._epoch = 0
+
+    def invalidate(self):
+        """call after parameters were modified through raw device pointers (the fused optimizer), which does not
+        bump their autograd version counters"""
+        self._epoch += 1
 
     def get(self, params, dtype: torch.dtype, transposed: bool):
         """params: tuple of [N_i, K] fp32 parameters, concatenated along N."""
         key = (tuple(id(p) for p in params), dtype, transposed)
-        ver = tuple((p._version, p.data_ptr()) for p in params)
+        ver = (self._epoch,) + tuple((p._version, p.data_ptr()) for p in params)
         hit = self._store.get(key)
         # id() values are recycled once a parameter is freed: an entry is valid only for the very same objects
         if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):

@@ -23,11 +23,18 @@ import torch
 import torch.distributed as dist
 
 
-class _Bucket:
-    __slots__ = ("flat", "params", "pending", "handle")
+ALIGN = 64      # every parameter starts on a 256-byte boundary inside its bucket (the kernels want 16-byte alignment)
 
-    def __init__(self, flat, params):
-        self.flat, self.params, self.pending, self.handle = flat, params, 0, None
+
+def _padded(n: int) -> int:
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "offsets", "pending", "handle")
+
+    def __init__(self, flat, params, offsets):
+        self.flat, self.params, self.offsets, self.pending, self.handle = flat, params, offsets, 0, None
 
 
 class GradReducer:
@@ -53,20 +60,21 @@ class GradReducer:
             if not cur:
                 return
             flat = torch.zeros(cur_n, device=cur[0].device, dtype=torch.float32)
-            off = 0
+            off, offsets = 0, []
             for p in cur:
                 n = p.numel()
                 p.grad = flat[off:off + n].view_as(p)
-                off += n
-            self.buckets.append(_Bucket(flat, cur))
+                offsets.append(off)
+                off += _padded(n)
+            self.buckets.append(_Bucket(flat, cur, offsets))
             cur, cur_n = [], 0
 
         for p in uniq:
             assert p.dtype == torch.float32, "master weights / gradients are fp32"
-            if cur and (cur_n + p.numel() > cap or p.device != cur[0].device):
+            if cur and (cur_n + _padded(p.numel()) > cap or p.device != cur[0].device):
                 flush()
             cur.append(p)
-            cur_n += p.numel()
+            cur_n += _padded(p.numel())
         flush()
         self._owner = {}
         for b in self.buckets:
@@ -82,12 +90,10 @@ class GradReducer:
             b.flat.zero_()
             b.pending = len(b.params)
             b.handle = None
-            off = 0
-            for p in b.params:                      # keep .grad pointing into the bucket
+            for p, off in zip(b.params, b.offsets):  # keep .grad pointing into the bucket
                 n = p.numel()
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * 4:
                     p.grad = b.flat[off:off + n].view_as(p)
-                off += n
 
     def _hook(self, p):
         b = self._owner[id(p)]
