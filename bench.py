@@ -14,7 +14,7 @@ gradient all-reduce overlapped with backward.  No optimizer step (the metric is 
 Weak scaling: 128 samples per GPU (global batch 1024 at 8 GPUs, BASELINE.json configs[3]).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (gemm_bf16_nt_kernel, MFMA-bound): algorithmic FLOPs of its launches
+  roofline     -- the dominant kernel (gemm_bf16_nt256_kernel, MFMA-bound): algorithmic FLOPs of its launches
                   / their HIP-event durations, measured live inside the timed steps;
   cpu_baseline -- the CPU oracle (a port: the reference is Python and cannot travel) timed on the host
                   cores on a bounded sample of the same workload (rank 0, N=1 only).
@@ -54,8 +54,8 @@ def flops_per_sample_executed(E: int) -> float:
 
 
 class GemmTimer:
-    """HIP-event timing of every launch of the dominant kernel (the bf16 NT GEMM behind Linear forward
-    and input-gradient) during the timed steps.  Events are recorded on the stream the kernel is
+    """HIP-event timing of every launch of the dominant kernel (gemm_bf16_nt256_kernel: the bf16 NT GEMM behind
+    Linear forward, the fused q|k|v projection and every input-gradient) during the timed steps.  Events are recorded on the stream the kernel is
     launched on (torch's current stream, which the C ABI receives)."""
 
     def __init__(self):
@@ -67,7 +67,7 @@ class GemmTimer:
         lib = ops.lib
         timer = self
 
-        def wrap(name, flops_of):
+        def wrap(name, flops_of, key_of):
             orig = getattr(lib, name)
 
             def call(*a):
@@ -77,7 +77,7 @@ class GemmTimer:
                 e0.record()
                 rc = orig(*a)
                 e1.record()
-                timer.recs.append((e0, e1, flops_of(a)))
+                timer.recs.append((e0, e1, flops_of(a), key_of(a)))
                 return rc
             return call
 
@@ -85,21 +85,49 @@ class GemmTimer:
             def __getattr__(self_, n):
                 return getattr(lib, n)
         proxy = LibProxy()
+        # the launches that gemm_bf16_nt_launch routes to gemm_bf16_nt256_kernel: bf16, M >= 1024, N % 256 == 0, K % 64 == 0
+        def nt256(M, N, K, dtype):
+            return 2.0 * M * N * K if (dtype == 1 and M >= 1024 and N % 256 == 0 and K % 64 == 0) else 0.0
         # meant_linear_fwd(x, ldx, w, bias, res, ldr, y, ldy, pre, M, N, K, epi, dtype, stream)
-        proxy.meant_linear_fwd = wrap("meant_linear_fwd", lambda a: 2.0 * a[9] * a[10] * a[11] if a[13] == 1 and a[11] % 64 == 0 else 0.0)
-        # meant_linear_bwd_dx(dy, lddy, wT, dx, lddx, M, N, K, dtype, stream)
-        proxy.meant_linear_bwd_dx = wrap("meant_linear_bwd_dx", lambda a: 2.0 * a[5] * a[6] * a[7] if a[8] == 1 and a[6] % 64 == 0 else 0.0)
+        proxy.meant_linear_fwd = wrap("meant_linear_fwd", lambda a: nt256(a[9], a[10], a[11], a[13]),
+                                      lambda a: (a[9], a[10], a[11], 2.0 * a[9] * a[10] * ((1 if a[4] else 0) + (1 if a[8] else 0))))
+        # meant_linear_bwd_dx(dy, lddy, wT, dx, lddx, M, N, K, dtype, stream): C[M,K] = dy[M,N] wT[K,N]^T
+        proxy.meant_linear_bwd_dx = wrap("meant_linear_bwd_dx", lambda a: nt256(a[5], a[7], a[6], a[8]), lambda a: (a[5], a[7], a[6], 0.0))
+        # meant_qkv_proj_fwd(x, ldx, w, bias, qkv, M, K, S, H, Dh, R, qa, qb, ka, kb, dtype, stream)
+        proxy.meant_qkv_proj_fwd = wrap("meant_qkv_proj_fwd", lambda a: nt256(a[5], 3 * a[8] * a[9], a[6], a[15]),
+                                        lambda a: (a[5], 3 * a[8] * a[9], a[6], 0.0))
         ops.lib = proxy
 
     def summary(self):
         tot_t, tot_f, n = 0.0, 0.0, 0
-        for e0, e1, f in self.recs:
+        for e0, e1, f, _ in self.recs:
             if f <= 0:
                 continue
             tot_t += e0.elapsed_time(e1) * 1e-3
             tot_f += f
             n += 1
         return n, tot_f, tot_t
+
+    def traffic_per_launch(self):
+        """HBM bytes per launch of the dominant kernel, averaged over the launches timed above, from the PMC table
+        in profiles/r01_nt256_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+        corrections applied; measured on the plain epilogue) plus the algorithmic bytes of the extra epilogue
+        operands (residual read / pre-activation write).  None if a launched shape is not in the table."""
+        path = os.path.join(ROOT, "profiles", "r01_nt256_hbm_traffic.json")
+        if not os.path.exists(path):
+            return None
+        table = json.load(open(path))["shapes"]
+        tot, n = 0.0, 0
+        for _, _, f, key in self.recs:
+            if f <= 0:
+                continue
+            M, N, K, extra = key
+            ent = table.get(f"{M},{N},{K}")
+            if ent is None:
+                return None
+            tot += ent["hbm_bytes"] + extra
+            n += 1
+        return tot / n if n else None
 
 
 def build_model(E: int, device):
@@ -241,8 +269,10 @@ def main():
         sps = world * B * args.steps / elapsed
         n, gf, gt = timer.summary()
         achieved = gf / gt / 1e12 if gt > 0 else 0.0
-        roofline = {"kernel": "gemm_bf16_nt_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        traffic = timer.traffic_per_launch() if B == 128 else None        # the PMC table was taken at 128 samples per GPU
+        roofline = {"kernel": "gemm_bf16_nt256_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None if traffic is None else round(traffic),
                     "launches_timed": n, "avg_launch_ms": round(gt / max(n, 1) * 1e3, 4),
                     "avg_launch_gflop": round(gf / max(n, 1) / 1e9, 2),
                     "whole_step_mfma_frac": round(sps / world * flops_per_sample_executed(E) / (PEAK_BF16_TFLOPS * 1e12), 4)}

@@ -1,0 +1,109 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full dimensions (lag 12, d 768, 12 heads,
+512 tokens, 224x224 p=16) -- where the CPU oracle would take too long to be the checker."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _full_model(dev, dtype):
+    import meant_amd
+    torch.manual_seed(11)
+    m = meant_amd.meant(768, 768, 4, 224, 224, 16, 12, 2, torch.nn.Embedding(5000, 768), num_heads=12, num_encoders=1).to(dev).eval()
+    m.compute_dtype = dtype
+    return m
+
+
+def _inputs(B, dev, seed=5):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ids = torch.randint(0, 5000, (B, 12, 512), generator=g).to(dev)
+    img = torch.randn(B, 12, 4, 224, 224, generator=g).to(dev)
+    mask = torch.ones(B, 12, 512)
+    for b in range(B):
+        mask[b, :, 512 - 37 * (b + 1):] = 0
+    return ids, img, mask.to(dev)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_samples_are_independent_and_batch_order_equivariant(dev, dtype):
+    """no cross-sample op anywhere.  A sample's output must not depend on what else is in the batch,
+    and permuting the batch permutes the output -- the property the data-parallel sharding rests on."""
+    m = _full_model(dev, dtype)
+    ids, img, mask = _inputs(6, dev)
+    with torch.no_grad():
+        full = m(ids, img, mask)
+        half = m(ids[2:5], img[2:5], mask[2:5])
+        perm = torch.tensor([3, 0, 5, 1, 4, 2], device=dev)
+        permuted = m(ids[perm], img[perm], mask[perm])
+    tol = 1e-6 if dtype == torch.float32 else 1e-6      # same kernels, same per-row arithmetic: bitwise in practice
+    assert (full[2:5] - half).abs().max().item() <= tol
+    assert (full[perm] - permuted).abs().max().item() <= tol
+    assert torch.isfinite(full).all() and ((full > 0) & (full < 1)).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_gradient_of_sum_is_sum_of_gradients(dev, dtype):
+    """linearity of backward over the batch: grads of a 4-sample batch == sum of the grads of its two halves
+    (what the gradient all-reduce assumes), at full dimensions"""
+    m = _full_model(dev, dtype)
+    ids, img, mask = _inputs(4, dev, seed=9)
+    tgt = torch.tensor([0, 1, 1, 0], device=dev)
+
+    def grads(sl):
+        m.zero_grad(set_to_none=True)
+        out = m(ids[sl], img[sl], mask[sl])
+        torch.nn.functional.cross_entropy(out, tgt[sl], reduction="sum").backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    g_all, g_a, g_b = grads(slice(0, 4)), grads(slice(0, 2)), grads(slice(2, 4))
+    big = max(v.norm().item() for v in g_all.values())
+    worst = 0.0
+    for k, v in g_all.items():
+        err = (v - (g_a[k] + g_b[k])).norm().item()
+        worst = max(worst, err / max(v.norm().item(), 1e-3 * big))
+    assert worst <= (2e-4 if dtype == torch.float32 else 2e-2), worst
+
+
+def test_attention_rows_are_convex_combinations(dev):
+    """softmax rows sum to one: with V == const the attention output equals that constant, for every mask
+    pattern (causal, padded tail, fully padded sequence) at S = 512 and N = 196"""
+    from meant_amd._lib import lib, check, BF16
+    H, Dh = 12, 64
+    D = H * Dh
+    for (G, S, causal) in [(24, 512, 1), (24, 196, 0)]:
+        qkv = torch.randn(G * S, 3 * D, device=dev) * 3
+        qkv[:, 2 * D:] = 0.75
+        qkv = qkv.bfloat16()
+        mask = torch.ones(G, S, device=dev)
+        mask[1, S // 3:] = 0
+        mask[2, :] = 0
+        o = torch.empty(G * S, D, device=dev, dtype=torch.bfloat16)
+        lse = torch.empty(G, H, S, 2, device=dev)
+        wsb = lib.meant_attn_ws(G, S, H, Dh, BF16)
+        ws = torch.empty(max(wsb, 16), device=dev, dtype=torch.uint8)
+        check(lib.meant_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), mask.data_ptr(), G, S, H, Dh, 1 / math.sqrt(D), causal,
+                                 BF16, ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream))
+        assert (o.float() - 0.75).abs().max().item() < 4e-3, (S, causal)
+
+
+def test_deterministic_forward_and_dropout_seeding(dev):
+    """two evaluations give identical outputs; train mode is reproducible under torch.manual_seed and differs from eval"""
+    m = _full_model(dev, torch.bfloat16)
+    ids, img, mask = _inputs(2, dev)
+    with torch.no_grad():
+        a, b = m(ids, img, mask), m(ids, img, mask)
+        assert torch.equal(a, b)
+        m.train()
+        torch.manual_seed(3); t1 = m(ids, img, mask)
+        torch.manual_seed(3); t2 = m(ids, img, mask)
+        torch.manual_seed(4); t3 = m(ids, img, mask)
+        m.eval()
+    assert torch.equal(t1, t2) and not torch.equal(t1, t3) and not torch.equal(t1, a)

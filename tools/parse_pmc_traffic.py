@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 counter CSVs of tools/pmc_nt256.py into profiles/<name>.json:
+   shape "M,N,K" -> HBM bytes per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024
+(gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE reports half of a wide coalesced read; both in KiB)."""
+import csv, glob, json, sys, collections
+sys.path.insert(0, ".")
+fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+SHAPES = [(786432, 2304, 768), (786432, 768, 768), (786432, 768, 2304),
+          (301056, 768, 1024), (301056, 2304, 768), (301056, 768, 768), (301056, 768, 2304)]
+
+def per_dispatch(d, counter):
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    vals = []
+    for r in csv.DictReader(open(f)):
+        if "gemm_bf16_nt256_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    vals.sort()
+    return [v for _, v in vals]
+
+fe, wr = per_dispatch(fetch_dir, "FETCH_SIZE"), per_dispatch(write_dir, "WRITE_SIZE")
+assert len(fe) == len(wr) == 3 * len(SHAPES), (len(fe), len(wr))
+res = {}
+for i, (M, N, K) in enumerate(SHAPES):
+    f = sum(fe[3 * i:3 * i + 3]) / 3 * 1024 * 2
+    w = sum(wr[3 * i:3 * i + 3]) / 3 * 1024
+    alg = (M * K + N * K + M * N) * 2
+    res[f"{M},{N},{K}"] = {"hbm_bytes": f + w, "fetch_bytes_corrected": f, "write_bytes": w, "algorithmic_bytes": alg,
+                           "ratio": round((f + w) / alg, 3)}
+json.dump({"kernel": "gemm_bf16_nt256_kernel", "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
+           "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)", "shapes": res},
+          open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
