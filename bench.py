@@ -202,8 +202,16 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal knobs for a one-GPU box: MEANT_DIST_BACKEND=gloo and MEANT_ALL_RANKS_ON_GPU0=1 run every rank on
+        # cuda:0 over gloo to exercise the N>1 code path; the real multi-GPU run uses RCCL ("nccl"), one GPU per rank
+        backend = os.environ.get("MEANT_DIST_BACKEND", "nccl")
+        if os.environ.get("MEANT_ALL_RANKS_ON_GPU0") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
