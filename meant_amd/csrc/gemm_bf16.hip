@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a,
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // swapped: acc = C^T tile
       __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
@@ -289,25 +289,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a,
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (a.bias && n + e < a.N) ? a.bias[n + e] : 0.f;
   const bool vec_ok = (n + 8 <= a.N) && ((a.ldc & 7) == 0) && (!a.residual || (a.ldr & 7) == 0);
+  // Operands were fed swapped (B as the MFMA "A"), so acc[i][j][e] = C[m = i*16 + frow][n = j*16 + 4*fkg + e]: a lane
+  // owns 4 CONSECUTIVE columns of one row and puts them into the staging tile with one ds_write_b128 (4x fewer LDS
+  // store instructions than the natural layout).  Each pass takes 32 rows from each of the two wave rows, so all 8
+  // waves write in every pass.
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     if (pass) __syncthreads();
-    if (wm == (pass >> 1)) {
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        const int i = (pass & 1) * 4 + ii;
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = pass * 2 + ii;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            Cs[(ii * 16 + fkg * 4 + e) * LDC + wn * 64 + j * 16 + frow] = acc[i][j][e];
-      }
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(Cs + (wm * 32 + ii * 16 + frow) * LDC + wn * 64 + j * 16 + fkg * 4) = acc[i][j];
     }
     __syncthreads();
 #pragma unroll 2
     for (int q = 0; q < 4; ++q) {
-      const int r = q * 16 + (tid >> 5);
-      const int64_t m = m0 + pass * 64 + r;
+      const int r = q * 16 + (tid >> 5);               // staging row: (wave row, 32 rows of this pass)
+      const int64_t m = m0 + (r >> 5) * 128 + pass * 32 + (r & 31);
       if (m >= a.M || n >= a.N) continue;
       float v[8];
       const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc);
