@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--encoders", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity-mode numerics)")
+    ap.add_argument("--two-streams", type=int, default=-1, help="override meant_amd.modules.TWO_STREAMS (0/1)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time the step with clip + fused AdamW (extra field)")
     args = ap.parse_args()
 
@@ -219,6 +220,9 @@ def main():
     from meant_amd.parallel import GradReducer
     from meant_amd.train import FusedAdamW, cross_entropy_on_probs
 
+    if args.two_streams >= 0:
+        import meant_amd.modules as _mm
+        _mm.TWO_STREAMS = bool(args.two_streams)
     timer = GemmTimer()
     timer.install()
     E, B = args.encoders, args.batch_per_gpu

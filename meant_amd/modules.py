@@ -35,6 +35,20 @@ from ._lib import EPI_NONE, EPI_GELU, EPI_SIGMOID
 # run the two Linears separately, exactly as the reference's module list does.
 COMPOSE_PRE_LINEAR = True
 
+# Run the vision stack of `meant` on a second HIP stream, concurrently with the language stack
+# (MEANT_TWO_STREAMS=0 in the environment turns it off).
+import os as _os
+TWO_STREAMS = _os.environ.get("MEANT_TWO_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 # ------------------------------------------------------------------------------------------
 # precision tier selection
 def resolve_compute_dtype(module: nn.Module, like: Optional[torch.Tensor]) -> torch.dtype:
@@ -375,11 +389,27 @@ class meant(nn.Module):
         words = _embed(self.embedding, tweets.reshape(B * self.lag, tweets.shape[2]), dt)
         if attention_mask is not None:
             attention_mask = attention_mask.reshape(B * self.lag, attention_mask.shape[2])
+        # The language and the vision stacks are independent until the pooled concat: with TWO_STREAMS the vision
+        # stack runs on a second HIP stream so that kernels with different bottlenecks (HBM-bound norms, load-path-bound
+        # GEMMs, issue-bound attention) of the two stacks can share the chip.  Autograd replays each backward op on the
+        # stream of its forward op, so the backward passes overlap the same way.
+        side = _side_stream(images.device) if (TWO_STREAMS and images.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
+                for enc in self.visionEncoders:
+                    img = enc(img)
         for enc in self.languageEncoders:
             words = enc(words, attention_mask)
-        img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
-        for enc in self.visionEncoders:
-            img = enc(img)
+        if side is not None:
+            main.wait_stream(side)
+            img.record_stream(main)
+        else:
+            img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
+            for enc in self.visionEncoders:
+                img = enc(img)
         fused = ops.meanpool_cat(words, img).view(B, self.lag, self.dim)
         for enc in self.temporal_encoding:
             fused = enc(fused)

@@ -31,10 +31,11 @@ def _padded(n: int) -> int:
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "handle")
+    __slots__ = ("flat", "params", "offsets", "pending", "handle", "streams")
 
     def __init__(self, flat, params, offsets):
         self.flat, self.params, self.offsets, self.pending, self.handle = flat, params, offsets, 0, None
+        self.streams = []
 
 
 class GradReducer:
@@ -90,6 +91,7 @@ class GradReducer:
             b.flat.zero_()
             b.pending = len(b.params)
             b.handle = None
+            b.streams = []
             for p, off in zip(b.params, b.offsets):  # keep .grad pointing into the bucket
                 n = p.numel()
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * 4:
@@ -98,7 +100,18 @@ class GradReducer:
     def _hook(self, p):
         b = self._owner[id(p)]
         b.pending -= 1
+        if p.is_cuda:
+            # the model may run its two encoder stacks on different HIP streams (modules.TWO_STREAMS): remember every
+            # stream that produced a gradient of this bucket, so that the collective is ordered after all of them
+            cur = torch.cuda.current_stream(p.device)
+            if all(cur != s for s in b.streams):
+                b.streams.append(cur)
         if b.pending == 0 and self.world > 1:
+            if p.is_cuda:
+                cur = torch.cuda.current_stream(p.device)
+                for s in b.streams:
+                    if s != cur:
+                        cur.wait_stream(s)
             op = dist.ReduceOp.SUM
             b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
 
