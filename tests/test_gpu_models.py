@@ -130,6 +130,52 @@ def test_model_vs_oracle_ragged(dev, dtype):
     compare_param_grads(ref, hip, dtype, "ragged")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_meant_vqa_full_width_vs_oracle(dev, dtype):
+    """BASELINE config 5 geometry: meant_vqa d=768, 12 heads, seq=512, 224x224, 3129 answer classes (B=2)"""
+    ref, hip = _mk("meant_vqa", (768, 768, 4, 224, 224, 16, 1, 3129), dict(num_heads=12, num_encoders=1), (3000, 768), dev)
+    r = np.random.RandomState(21)
+    ids = t(r.randint(0, 3000, (2, 512)).astype("int64"))
+    img = t(r.standard_normal((2, 4, 224, 224)).astype("float32"))
+    mask = torch.ones(2, 512)
+    mask[1, 300:] = 0
+    tgt = torch.tensor([17, 3000])
+    out_r = ref(ids, img, mask)
+    torch.nn.functional.cross_entropy(out_r, tgt).backward()
+    hip.compute_dtype = dtype
+    out = hip(ids.to(dev), img.to(dev), mask.to(dev))
+    assert out.shape == (2, 3129)
+    torch.nn.functional.cross_entropy(out, tgt.to(dev)).backward()
+    assert_close(out, out_r, TOL[dtype]["out"], "out")
+    ref_p = dict(ref.named_parameters())
+    floor = norm_floor([p.grad.double().norm().item() for p in ref_p.values() if p.grad is not None], dtype)
+    for k, p in hip.named_parameters():
+        if ref_p[k].grad is None:
+            continue
+        a, b = p.grad.double().norm().item(), ref_p[k].grad.double().norm().item()
+        assert abs(a - b) <= TOL[dtype]["gnorm"] * max(b, floor), (k, a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_default_eight_heads_head_dim_96(dev, dtype):
+    """the reference's own runs never pass num_heads (default 8 -> head dim 96, rotary dim 48 for the patches): the bf16
+    tier serves it through the widening attention path"""
+    ref, hip = _mk("meant", (768, 768, 4, 64, 64, 16, 2, 2), dict(num_encoders=1), (500, 768), dev)     # num_heads default 8
+    r = np.random.RandomState(22)
+    ids = t(r.randint(0, 500, (2, 2, 40)).astype("int64"))
+    img = t(r.standard_normal((2, 2, 4, 64, 64)).astype("float32"))
+    mask = torch.ones(2, 2, 40)
+    mask[0, :, 33:] = 0
+    tgt = torch.tensor([1, 0])
+    out_r = ref(ids, img, mask)
+    torch.nn.functional.cross_entropy(out_r, tgt).backward()
+    hip.compute_dtype = dtype
+    out = hip(ids.to(dev), img.to(dev), mask.to(dev))
+    torch.nn.functional.cross_entropy(out, tgt.to(dev)).backward()
+    assert_close(out, out_r, TOL[dtype]["out"], "out")
+    compare_param_grads(ref, hip, dtype, "heads8")
+
+
 def test_autocast_selects_bf16_and_state_dict_roundtrip(dev):
     import meant_amd
     m = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2).to(dev).eval()
