@@ -249,9 +249,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a,
   for (int kt = 0; kt < nk; ++kt) {
     char* cur = smem + (kt & 1) * 2 * T2_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * 2 * T2_BYTES;
-    if (kt + 1 < nk) {
+    // Only waves 0-3 issue DMA (all 64 pieces of the next stage, 16 each): a wave issues no MFMA while it feeds pieces
+    // to the address unit, and the two waves of a SIMD (w, w+4) would otherwise both do that right after the barrier
+    // with the matrix pipe idle.  This way waves 4-7 start their MFMAs at once and their partners follow (+5 % on the
+    // K-loop; issuing late instead -- after the MFMAs -- exposes the load latency at the barrier and measured -10 %).
+    const bool late = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    if (!late && kt + 1 < nk) {
       nt256_stage(a.A, a.lda, m0, a.M, (int64_t)(kt + 1) * BK, nxt, wave, lane);
       nt256_stage(a.B, a.ldb, n0, a.N, (int64_t)(kt + 1) * BK, nxt + T2_BYTES, wave, lane);
+      nt256_stage(a.A, a.lda, m0, a.M, (int64_t)(kt + 1) * BK, nxt, wave + 4, lane);
+      nt256_stage(a.B, a.ldb, n0, a.N, (int64_t)(kt + 1) * BK, nxt + T2_BYTES, wave + 4, lane);
     }
     const char* At = cur + (wm * 128) * 128;
     const char* Bt = cur + T2_BYTES + (wn * 64) * 128;
