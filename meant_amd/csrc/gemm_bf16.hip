@@ -506,9 +506,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * 2 * TN2_TILE;
     char* nxt = smem + ((t + 1) & 1) * 2 * TN2_TILE;
-    if (t + 1 < nt) {
+    // as in the NT kernel: waves 0-3 issue all DMA pieces, their SIMD partners (waves 4-7) go straight to the MFMAs
+    if (t + 1 < nt && __builtin_amdgcn_readfirstlane(threadIdx.x) < 256) {
       tn256_stage(dY, lddy, mbeg + (int64_t)(t + 1) * TN_BKM, mend, n0, nxt, wave, lane);
       tn256_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, nxt + TN2_TILE, wave, lane);
+      tn256_stage(dY, lddy, mbeg + (int64_t)(t + 1) * TN_BKM, mend, n0, nxt, wave + 4, lane);
+      tn256_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, nxt + TN2_TILE, wave + 4, lane);
     }
     const unsigned cbase = lds_addr(cur);
     // fragment reads are software-pipelined one k-step ahead: while the MFMAs of k-step ks run, the 12 transposed
