@@ -157,10 +157,16 @@ __device__ __forceinline__ void rotary_adjoint_regs(f32x16 (&acc)[2], const floa
 
 // ------------------------------------------------------------------------------------------------
 // key-padding mask -> additive bias in log2 units, bias2[g][key] = (1 - mask) * -1e9 * log2e (0 for real keys,
-// -inf for the padding keys >= S of the last tile), and flags[g][tile] != 0 iff the tile needs the bias or the
-// tail treatment at all.  Padding is a suffix in practice, so most tiles take the bias-free path.
+// -inf for the padding keys >= S of the last tile), and flags[g][tile]:
+//   bit 0: the tile needs the bias or the tail treatment at all.  Padding is a suffix in practice, so most tiles
+//          take the bias-free path.
+//   bit 1: the tile can be skipped outright: all of its 64 keys are dead (bias <= -1e8, so exp2(t - m) underflows
+//          to exactly 0 against any live key) AND every query row of the group is guaranteed a live visible key
+//          (key 0 under the causal mask, any key otherwise) -- rows with no live key keep the reference's uniform
+//          softmax over the padding and therefore need every tile.
+constexpr float DEAD_BIAS = -1e8f, LIVE_BIAS = -1e6f;
 __global__ __launch_bounds__(64) void attn_prep_mask_kernel(const float* __restrict__ km, float* __restrict__ bias2,
-                                                             int* __restrict__ flags, int S, int nt) {
+                                                             int* __restrict__ flags, int S, int nt, int causal) {
   const int g = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
   const int key = t * KV_TILE + lane;
   float b = 0.f;
@@ -168,7 +174,17 @@ __global__ __launch_bounds__(64) void attn_prep_mask_kernel(const float* __restr
   else if (km) b = fmaf(km[(int64_t)g * S + key], PADL2, -PADL2);
   bias2[((int64_t)g * nt + t) * KV_TILE + lane] = b;
   const int any = __any(b != 0.f);
-  if (lane == 0) flags[(int64_t)g * nt + t] = any;
+  int skip = 0;
+  if (km && __all(b <= DEAD_BIAS)) {
+    const float* kg = km + (int64_t)g * S;
+    if (causal) skip = fmaf(kg[0], PADL2, -PADL2) >= LIVE_BIAS;
+    else {
+      bool live = false;
+      for (int k = lane; k < S; k += 64) live |= fmaf(kg[k], PADL2, -PADL2) >= LIVE_BIAS;
+      skip = __any(live);
+    }
+  }
+  if (lane == 0) flags[(int64_t)g * nt + t] = any | (skip << 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 
   int kend = S;                                      // keys needed by this block
   if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
-  const int nt = (kend + KV_TILE - 1) / KV_TILE;
+  int nt = (kend + KV_TILE - 1) / KV_TILE;
+  while (nt > 1 && (flg[nt - 1] & 2)) --nt;          // trailing all-padding tiles contribute exactly 0
 
   f32x16 oacc[2];
 #pragma unroll
@@ -234,7 +251,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const int k0 = t * KV_TILE;
-    const bool active = !a.causal || (k0 <= q0 + 31);      // wave-uniform: tile not entirely above the diagonal
+    const int flag = flg[t];
+    const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));   // wave-uniform: tile not entirely above the diagonal / all padding
     if (active && q0 < S) {
       const char* Kt = smem + buf * 2 * TILE_B;
       const char* Vt = Kt + TILE_B;
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
       // diagonal, nor padding, nor the end of the sequence (most of them) take the mask-free path: one multiply and
       // one max per score.  O and l are rescaled only on tiles where some lane's running max actually moves.
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);   // tile touches the diagonal for some query of this wave
-      const bool special = diag || (flg[t] != 0);
+      const bool special = diag || (flag & 1);
       float tmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       if (!special) {
 #pragma unroll
@@ -399,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 
   int kend = S;
   if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
-  const int nt = (kend + KV_TILE - 1) / KV_TILE;
+  int nt = (kend + KV_TILE - 1) / KV_TILE;
+  while (nt > 1 && (flg[nt - 1] & 2)) --nt;          // trailing all-padding tiles contribute exactly 0
 
   f32x16 dqacc[2];
 #pragma unroll
@@ -421,12 +440,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const int k0 = t * KV_TILE;
-    const bool active = !a.causal || (k0 <= q0 + 31);
+    const int flag = flg[t];
+    const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));
     if (active && q0 < S) {
       const char* Kt = smem + buf * 2 * TILE_B;
       const char* Vt = Kt + TILE_B;
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);
-      const bool special = diag || (flg[t] != 0);
+      const bool special = diag || (flag & 1);
       const unsigned kaddr = lds_addr(Kt);
       auto body = [&](auto SB) {
         constexpr int sb = decltype(SB)::value;
@@ -523,8 +543,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dkacc[b][e] = 0.f; dvacc[b][e] = 0.f; }
 
-  const int t0 = a.causal ? kb0 / 64 : 0;            // first query tile that can see this block's keys
+  // keys of an all-padding tile get exactly zero dK / dV (flags bit 1): their waves sit the loop out, and a block
+  // made of such tiles only writes its zeros
+  const int* flg = a.flags + (int64_t)g * ntile;
+  const bool wave_dead = key0 < S && (flg[key0 / KV_TILE] & 2);
+  const int kt_lo = kb0 / KV_TILE, kt_hi = (kb0 + 64 < S) ? kt_lo + 1 : kt_lo;
+  const bool block_dead = (flg[kt_lo] & 2) && (flg[kt_hi] & 2);
   const int nt = (S + 63) / 64;
+  const int t0 = block_dead ? nt : (a.causal ? kb0 / 64 : 0);   // first query tile that can see this block's keys
 
   // per-tile statistics by DMA too: st[0..127] = interleaved (m, log l) pairs of the 64 queries, st[128..191] = delta
   auto stage = [&](int t, int buf) {
@@ -552,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     const int buf = (t - t0) & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const int qt0 = t * 64;
-    const bool active = (key0 < S) && (!a.causal || (qt0 + 63 >= key0));
+    const bool active = (key0 < S) && !wave_dead && (!a.causal || (qt0 + 63 >= key0));
     if (active) {
       const char* Qt = smem + buf * 2 * TILE_B;
       const char* dOt = Qt + TILE_B;
@@ -689,7 +715,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   const int nt = (int)ceil_div(S, KV_TILE);
   float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
-  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt);
+  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal);
   MEANT_LAUNCH_CHECK("attn_prep_mask");
   FwdArgs a{qkv, o, lse, bias2, flags, (int)S, H, scale, causal};
   static bool attr_set = false;
@@ -715,7 +741,7 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
   const int nt = (int)ceil_div(S, KV_TILE);
   float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
-  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt);
+  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal);
   MEANT_LAUNCH_CHECK("attn_prep_mask");
   BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, (int)S, H, scale, causal, rot};
   static bool attr_set = false;

@@ -253,6 +253,35 @@ def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_text_attention_padding_patterns(M, O, dev, dtype):
+    """the bf16 kernels skip key tiles that are all padding when key 0 is live; every pattern that does or does not
+    qualify (suffix at and off tile boundaries, prefix, hole, one live key, nothing live) must match the oracle"""
+    G, S, H, d = 7, 320, 2, 128
+    ref, hip = _attn_pair(M, O, "xpos", H, d, dev)
+    rs = np.random.RandomState(99)
+    x = t(rs.standard_normal((G, S, d)).astype("float32"))
+    dy = t(rs.standard_normal((G, S, d)).astype("float32"))
+    mask = torch.ones(G, S)
+    mask[0, 64:] = 0            # suffix on a tile boundary: tiles 1..4 skipped
+    mask[1, 131:] = 0           # suffix off a boundary: tile 2 partial, 3..4 skipped
+    mask[2, :70] = 0            # prefix: key 0 dead -> nothing may be skipped (rows 0..69 see only padding)
+    mask[3, 64:192] = 0         # hole: tiles 1..2 skipped in the middle
+    mask[4, 1:] = 0             # one live key
+    mask[5, :] = 0              # nothing live
+    xq, dyq = x.to(dtype).float(), dy.to(dtype).float()
+    xr = xq.clone().requires_grad_()
+    yr = ref(xr, mask)
+    yr.backward(dyq)
+    xh = x.to(dev).to(dtype).requires_grad_()
+    yh = hip(xh, mask.to(dev))
+    yh.backward(dy.to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert_close(yh, yr, tol["out"] * (1 if dtype == torch.float32 else 4), "y")
+    assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+    compare_param_grads(ref, hip, dtype, "xpos")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_temporal_golden(M, O, dev, golden, dtype):
     g = golden("temporal_h12_d1536_l12")
     ref, hip = pair(O.temporal(12, 1536), M.temporal(12, 1536), 4321, dev)
