@@ -14,7 +14,7 @@ gradient all-reduce overlapped with backward.  No optimizer step (the metric is 
 Weak scaling: 128 samples per GPU (global batch 1024 at 8 GPUs, BASELINE.json configs[3]).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (gemm_bf16_nt256_kernel, MFMA-bound): algorithmic FLOPs of its launches
+  roofline     -- the dominant kernel (gemm_bf16_nt256s_kernel, MFMA-bound): algorithmic FLOPs of its launches
                   / their HIP-event durations, measured live inside the timed steps;
   cpu_baseline -- the CPU oracle (a port: the reference is Python and cannot travel) timed on the host
                   cores on a bounded sample of the same workload (rank 0, N=1 only).
@@ -54,7 +54,7 @@ def flops_per_sample_executed(E: int) -> float:
 
 
 class GemmTimer:
-    """HIP-event timing of every launch of the dominant kernel (gemm_bf16_nt256_kernel: the bf16 NT GEMM behind
+    """HIP-event timing of every launch of the dominant kernel (gemm_bf16_nt256s_kernel: the streaming bf16 NT GEMM behind
     Linear forward, the fused q|k|v projection and every input-gradient) during the timed steps.  Events are recorded on the stream the kernel is
     launched on (torch's current stream, which the C ABI receives)."""
 
@@ -85,9 +85,9 @@ class GemmTimer:
             def __getattr__(self_, n):
                 return getattr(lib, n)
         proxy = LibProxy()
-        # the launches that gemm_bf16_nt_launch routes to gemm_bf16_nt256_kernel: bf16, M >= 1024, N % 256 == 0, K % 64 == 0
+        # the launches that gemm_bf16_nt_launch routes to gemm_bf16_nt256s_kernel: bf16, M >= 1024, M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128
         def nt256(M, N, K, dtype):
-            return 2.0 * M * N * K if (dtype == 1 and M >= 1024 and N % 256 == 0 and K % 64 == 0) else 0.0
+            return 2.0 * M * N * K if (dtype == 1 and M >= 1024 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128) else 0.0
         # meant_linear_fwd(x, ldx, w, bias, res, ldr, y, ldy, pre, M, N, K, epi, dtype, stream)
         proxy.meant_linear_fwd = wrap("meant_linear_fwd", lambda a: nt256(a[9], a[10], a[11], a[13]),
                                       lambda a: (a[9], a[10], a[11], 2.0 * a[9] * a[10] * ((1 if a[4] else 0) + (1 if a[8] else 0))))
@@ -298,7 +298,7 @@ def main():
         n, gf, gt = timer.summary()
         achieved = gf / gt / 1e12 if gt > 0 else 0.0
         traffic = timer.traffic_per_launch() if B == 128 else None        # the PMC table was taken at 128 samples per GPU
-        roofline = {"kernel": "gemm_bf16_nt256_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+        roofline = {"kernel": "gemm_bf16_nt256s_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic),
                     "launches_timed": n, "avg_launch_ms": round(gt / max(n, 1) * 1e3, 4),

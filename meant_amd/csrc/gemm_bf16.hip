@@ -326,6 +326,200 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a,
   }
 }
 
+// The 160 KiB of LDS can hold a ring of FIVE 32 KiB operand tiles (A_0 B_0 A_1 B_1 A_2 ...; tile t lives in slot
+// t mod 5) instead of two 64 KiB stages.  While step n computes from A_n / B_n, the DMA fills B_{n+1} (needed next
+// step) and A_{n+2} (needed in two), so only half of a stage has to make the issue -> land round trip within one
+// K-step; the barrier waits with a COUNTED vmcnt for exactly the tiles the next step needs.  (The two-stage kernel
+// above is bound by that round trip: 64 KiB per CU through a 64 B/clk address path is 1024 clocks of issue alone
+// before the last piece even starts its trip.)
+constexpr int RING = 5;
+
+// ------------------------------------------------------------------------------------------------
+// Streaming (persistent) NT kernel: the kernel this file is built around for the tall GEMMs of the step.
+//
+// Same 256 x 256 tile and 8 waves as gemm_bf16_nt256_kernel, staged through the 5-slot ring; one workgroup per CU walks a
+// SEQUENCE of tiles and treats all their K-steps as one stream: the ring keeps prefetching across the tile boundary
+// (B of the next step, A of the one after -- whichever tile they belong to), and the epilogue needs no workgroup-wide
+// staging buffer: each wave transposes its 16 x 64 pieces through a private 4 KiB patch in the two ring slots the
+// finished step has just vacated and stores complete 128-byte lines.  What that buys at K = 768, where a tile is only
+// 12 K-steps long:
+//   * no prologue bubble per tile (the first operands of tile t+1 land while tile t still computes);
+//   * no epilogue bubble: the 128 KiB of output per tile are fire-and-forget stores that drain under the next tile's
+//     K-loop.  In the one-tile-per-workgroup kernels all 256 CUs finish together and write 32 MiB in one burst while
+//     the matrix pipes wait for the stores (measured: 4 us of a 24 us tile for the stores, 5 us for the rest of the
+//     prologue/epilogue).
+// Requirements (the launcher falls back to the kernels above otherwise): M % 256 == 0, N % 256 == 0, K % 64 == 0,
+// K >= 128, ldc % 8 == 0.
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk = (int)(a.K / BK);
+  const int ntiles = ntm * ntn, G = gridDim.x;
+  // workgroup b runs on XCD b % 8 (round-robin dispatch): in every round each XCD takes G/8 consecutive tile ids,
+  // i.e. a few rows of tiles that share their A panels and all of W through that XCD's L2
+  int tile = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+
+  // waves 0-3 issue all DMA; wave w owns pieces 4w..4w+3 and 4(w+4)..4(w+4)+3 (1 KiB = 8 rows of 128 B) of every tile
+  const bool issuer = wave < 4;
+  unsigned oA[8], oB[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int piece = p < 4 ? wave * 4 + p : (wave + 4) * 4 + p - 4;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    oA[p] = (unsigned)(r * a.lda + c * 8);
+    oB[p] = (unsigned)(r * a.ldb + c * 8);
+  }
+  auto stage = [&](const bf16* base, const unsigned (&off)[8], int slot) {
+    char* dst = smem + slot * T2_BYTES;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) glds16(base + off[p], dst + (p < 4 ? wave * 4 + p : (wave + 4) * 4 + p - 4) * 1024);
+  };
+  auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
+    const int tm = t / ntn, tn = t - tm * ntn;
+    m0 = (int64_t)tm * B2;
+    n0 = (int64_t)tn * B2;
+    pa = a.A + m0 * a.lda;
+    pb = a.B + n0 * a.ldb;
+  };
+
+  const bf16 *pA, *pB, *pAn = nullptr, *pBn = nullptr;      // operand origins of this tile and of the next one
+  int64_t m0, n0, m0n = 0, n0n = 0;
+  origin(tile, pA, pB, m0, n0);
+  int next = tile + G;
+  bool has_next = next < ntiles;
+  if (has_next) origin(next, pAn, pBn, m0n, n0n);
+
+  if (issuer) {
+    stage(pA, oA, 0);
+    stage(pB, oB, 1);
+    stage(pA + BK, oA, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int frow = lane & 15, fkg = lane >> 4;
+  int sA = 0;                                          // ring slot of the current step's A tile; B sits in the next one
+  for (;;) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int sB = sA + 1 == RING ? 0 : sA + 1;
+      const int s3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, s4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
+      const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+      const bool more2 = in2 || has_next;
+      if (issuer && !(DBG & 1)) {
+        if (in1) stage(pB + (int64_t)(kt + 1) * BK, oB, s3);
+        else if (has_next) stage(pBn, oB, s3);
+        if (in2) stage(pA + (int64_t)(kt + 2) * BK, oA, s4);
+        else if (has_next) stage(pAn + (int64_t)(kt + 2 - nk) * BK, oA, s4);
+      }
+      const char* At = smem + sA * T2_BYTES + (wm * 128) * 128;
+      const char* Bt = smem + sB * T2_BYTES + (wn * 64) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[8], bfr[4];
+        const int c = ks * 4 + fkg;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = i * 16 + frow;
+          af[i] = *reinterpret_cast<const bf16x8*>(At + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = j * 16 + frow;
+          bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // swapped: acc = C^T tile
+        __builtin_amdgcn_s_setprio(0);
+      }
+      // the next step needs its A tile (issued a step ago) and its B tile (issued above); the A tile after that may
+      // stay in flight.  The output stores of the previous tile are older than all of these and retire first.
+      asm volatile("" ::: "memory");
+      if (more2 && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      sA = sA + 2 >= RING ? sA + 2 - RING : sA + 2;
+    }
+
+    // ---- epilogue: accumulators -> per-wave LDS patch (fp32, XOR-swizzled) -> 128-byte row segments -------------
+    // The two ring slots of the step that just finished are free until the next step issues its DMA, and every wave
+    // only talks to its own 4 KiB patch in each of them, so there is no workgroup barrier in here.  Lane layout in:
+    // acc[i][j] = C[i*16 + frow][j*16 + 4*fkg .. +3]; out: lane l owns 8 consecutive columns (l & 7) * 8 of row
+    // (l >> 3) + 8h, i.e. one store instruction writes 8 complete 128-byte lines.
+    if (!(DBG & 4)) {
+      const int f3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, f4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
+      float* patch[2] = {reinterpret_cast<float*>(smem + f3 * T2_BYTES + wave * 4096),
+                         reinterpret_cast<float*>(smem + f4 * T2_BYTES + wave * 4096)};
+      const int orow = lane >> 3, oc = lane & 7;
+      const int64_t n = n0 + wn * 64 + oc * 8;
+      float bias[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
+      // patch I/O goes through inline asm: hipcc does not know the DMA ring is quiescent here and would put a
+      // vmcnt(0) -- i.e. a full drain of the output stores -- in front of every plain LDS store
+      const unsigned pw0 = lds_addr(patch[0]) + frow * 256, pw1 = lds_addr(patch[1]) + frow * 256;
+#pragma unroll
+      for (int ip = 0; ip < 4; ++ip) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = ip * 2 + u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            asm volatile("ds_write_b128 %0, %1" ::"v"((u ? pw1 : pw0) + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
+        }
+        f32x4 lo[2][2], hi[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = orow + 8 * h;
+            const unsigned base = lds_addr(patch[u]) + r * 256;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(lo[u][h]) : "v"(base + (((2 * oc) ^ r) << 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(hi[u][h]) : "v"(base + (((2 * oc + 1) ^ r) << 4)) : "memory");
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = ip * 2 + u;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = orow + 8 * h;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[u][h][e] : hi[u][h][e - 4]) + bias[e];
+            nt_store_row8(a, m0 + wm * 128 + i * 16 + r, n, v, true);
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    // the patches live in the ring slots the next step's DMA is about to fill: every wave must be out of them first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    tile = next; pA = pAn; pB = pBn; m0 = m0n; n0 = n0n;
+    next += G;
+    has_next = next < ntiles;
+    if (has_next) origin(next, pAn, pBn, m0n, n0n);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // TN kernel: dW[n][k] += sum_m dY[m][n] X[m][k].  LDS tiles are [64 m][128 cols] (256-byte rows).
 constexpr int TN_BKM = 64;
@@ -591,12 +785,21 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   static bool attr256_set = false;
   if (!attr256_set) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
     attr256_set = true;
   }
   if (a.M >= 1024 && a.N % 256 == 0) {              // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP)
     const int64_t ntm2 = ceil_div(a.M, B2), ntn2 = a.N / B2;
     MEANT_REQUIRE(ntm2 * ntn2 < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
-    hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+    // MEANT_NT_STREAM=0 forces the one-tile-per-workgroup kernel (A/B measurements)
+    static const bool stream_ok = !(getenv("MEANT_NT_STREAM") && atoi(getenv("MEANT_NT_STREAM")) == 0);
+    if (stream_ok && a.M % B2 == 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
+      const int ncu = meant_num_cus() & ~7;
+      const int grid = (int)(ntm2 * ntn2 < ncu ? ((ntm2 * ntn2 + 7) / 8) * 8 : ncu);
+      hipLaunchKernelGGL(gemm_bf16_nt256s_kernel<0>, dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+    } else {
+      hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+    }
     MEANT_LAUNCH_CHECK("gemm_bf16_nt256");
     return MEANT_OK;
   }
