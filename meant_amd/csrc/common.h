@@ -87,6 +87,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU for the bf16 tier's GEMM epilogues, where libm's erff (~40 VALU instructions per element) is paid on
+// 65536 outputs per tile with the matrix pipe idle: Phi(x) through the Abramowitz-Stegun 7.1.26 rational form of erfc
+// (|error| <= 7.5e-8 in Phi, three orders below bf16 rounding), one v_rcp and one v_exp per element, written so that
+// the negative tail has no cancellation.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 0.5 * erfc(|x|/sqrt2)
+  const float phi = x < 0.f ? half_erfc : 1.0f - half_erfc;
+  return x * phi;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);

@@ -67,6 +67,39 @@ __device__ __forceinline__ void nt_stage(const bf16* __restrict__ g, int64_t ld,
 // rounds once and stores 16 bytes.  Rotary epilogue (fused QKV projection): columns are [q | k | v] blocks of
 // rot_D = H*Dh columns, a head is Dh columns, lanes c < R of every q/k head are rotated with the tables of the
 // token's position m mod S:  out[c] = t[c]*A[pos,c] + rot(t)[c]*B[pos,c]  (meant/rotary_embedding_torch.py:31-44).
+// the tail of nt_store_row8's vector path without the store: activation, residual, one rounding
+__device__ __forceinline__ bf16x8 nt_finish_row8(const GemmBf16Args& a, int64_t m, int64_t n, float (&v)[8]) {
+  if (a.epilogue & MEANT_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+  }
+  if (a.epilogue & MEANT_EPI_SIGMOID) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+  }
+  if (a.residual) {
+    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+  return o;
+}
+
+// rotate 8 consecutive columns (4 pairs) with table rows A[0..7], B[0..7]
+__device__ __forceinline__ void rot_apply8(float (&v)[8], const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const float t0 = v[e], t1 = v[e + 1];
+    const float A0 = e < 4 ? a0[e] : a1[e - 4], A1 = e < 4 ? a0[e + 1] : a1[e - 3];
+    const float B0 = e < 4 ? b0[e] : b1[e - 4], B1 = e < 4 ? b0[e + 1] : b1[e - 3];
+    v[e] = t0 * A0 - t1 * B0;
+    v[e + 1] = t1 * A1 + t0 * B1;
+  }
+}
+
 __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, int64_t n, float (&v)[8], bool vec_ok) {
   if (vec_ok) {
     if (a.preact) {
@@ -82,21 +115,13 @@ __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, 
         const int pos = (int)(m % a.rot_S);
         const float* A = (sec ? a.rot_ka : a.rot_qa) + (int64_t)pos * a.rot_R + c;
         const float* B = (sec ? a.rot_kb : a.rot_qb) + (int64_t)pos * a.rot_R + c;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(A), a1 = *reinterpret_cast<const f32x4*>(A + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(B), b1 = *reinterpret_cast<const f32x4*>(B + 4);
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const float t0 = v[e], t1 = v[e + 1];
-          const float A0 = e < 4 ? a0[e] : a1[e - 4], A1 = e < 4 ? a0[e + 1] : a1[e - 3];
-          const float B0 = e < 4 ? b0[e] : b1[e - 4], B1 = e < 4 ? b0[e + 1] : b1[e - 3];
-          v[e] = t0 * A0 - t1 * B0;
-          v[e + 1] = t1 * A1 + t0 * B1;
-        }
+        rot_apply8(v, *reinterpret_cast<const f32x4*>(A), *reinterpret_cast<const f32x4*>(A + 4),
+                   *reinterpret_cast<const f32x4*>(B), *reinterpret_cast<const f32x4*>(B + 4));
       }
     }
     if (a.epilogue & MEANT_EPI_GELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
     }
     if (a.epilogue & MEANT_EPI_SIGMOID) {
 #pragma unroll
@@ -115,7 +140,7 @@ __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, 
     for (int e = 0; e < 8 && n + e < a.N; ++e) {
       float x = v[e];
       if (a.preact) a.preact[m * a.ldc + n + e] = (bf16)x;
-      if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf(x);
+      if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf_fast(x);
       if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
       if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
       a.C[m * a.ldc + n + e] = (bf16)x;
@@ -350,7 +375,7 @@ constexpr int RING = 5;
 //     prologue/epilogue).
 // Requirements (the launcher falls back to the kernels above otherwise): M % 256 == 0, N % 256 == 0, K % 64 == 0,
 // K >= 128, ldc % 8 == 0.
-template <int DBG>
+template <int DBG, bool ROT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a, int ntm, int ntn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,21 +387,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   int tile = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
 
-  // waves 0-3 issue all DMA; wave w owns pieces 4w..4w+3 and 4(w+4)..4(w+4)+3 (1 KiB = 8 rows of 128 B) of every tile
+  // waves 0-3 issue all DMA; wave w owns pieces 4w..4w+3 and 4(w+4)..4(w+4)+3 (1 KiB = 8 rows of 128 B) of every tile.
+  // Piece p of a wave starts 8 * pp rows below its first one (pp = p, or p + 12 for the second group), which is a
+  // uniform offset; the swizzled 16-byte column of a lane only alternates between two values (c0, c0 ^ 4) with the
+  // parity of p.  So a lane keeps two 32-bit offsets per operand and everything else lives in scalar registers.
   const bool issuer = wave < 4;
-  unsigned oA[8], oB[8];
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int piece = p < 4 ? wave * 4 + p : (wave + 4) * 4 + p - 4;
-    const int r = piece * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    oA[p] = (unsigned)(r * a.lda + c * 8);
-    oB[p] = (unsigned)(r * a.ldb + c * 8);
-  }
-  auto stage = [&](const bf16* base, const unsigned (&off)[8], int slot) {
+  const int r0 = wave * 32 + (lane >> 3);
+  const int c0 = (lane & 7) ^ ((r0 >> 1) & 7);
+  const unsigned oA[2] = {(unsigned)(r0 * a.lda + c0 * 8), (unsigned)(r0 * a.lda + (c0 ^ 4) * 8)};
+  const unsigned oB[2] = {(unsigned)(r0 * a.ldb + c0 * 8), (unsigned)(r0 * a.ldb + (c0 ^ 4) * 8)};
+  auto stage = [&](const bf16* base, const unsigned (&off)[2], int64_t ld, int slot) {
     char* dst = smem + slot * T2_BYTES;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) glds16(base + off[p], dst + (p < 4 ? wave * 4 + p : (wave + 4) * 4 + p - 4) * 1024);
+    for (int p = 0; p < 8; ++p) {
+      const int pp = p < 4 ? p : p + 12;
+      glds16(base + (int64_t)(8 * pp) * ld + off[p & 1], dst + (wave * 4 + pp) * 1024);
+    }
   };
   auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
     const int tm = t / ntn, tn = t - tm * ntn;
@@ -394,9 +420,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   if (has_next) origin(next, pAn, pBn, m0n, n0n);
 
   if (issuer) {
-    stage(pA, oA, 0);
-    stage(pB, oB, 1);
-    stage(pA + BK, oA, 2);
+    stage(pA, oA, a.lda, 0);
+    stage(pB, oB, a.ldb, 1);
+    stage(pA + BK, oA, a.lda, 2);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -417,10 +443,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
       const bool more2 = in2 || has_next;
       if (issuer && !(DBG & 1)) {
-        if (in1) stage(pB + (int64_t)(kt + 1) * BK, oB, s3);
-        else if (has_next) stage(pBn, oB, s3);
-        if (in2) stage(pA + (int64_t)(kt + 2) * BK, oA, s4);
-        else if (has_next) stage(pAn + (int64_t)(kt + 2 - nk) * BK, oA, s4);
+        if (in1) stage(pB + (int64_t)(kt + 1) * BK, oB, a.ldb, s3);
+        else if (has_next) stage(pBn, oB, a.ldb, s3);
+        if (in2) stage(pA + (int64_t)(kt + 2) * BK, oA, a.lda, s4);
+        else if (has_next) stage(pAn + (int64_t)(kt + 2 - nk) * BK, oA, a.lda, s4);
       }
       const char* At = smem + sA * T2_BYTES + (wm * 128) * 128;
       const char* Bt = smem + sB * T2_BYTES + (wn * 64) * 128;
@@ -472,39 +498,90 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       for (int e = 0; e < 8; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
       // patch I/O goes through inline asm: hipcc does not know the DMA ring is quiescent here and would put a
       // vmcnt(0) -- i.e. a full drain of the output stores -- in front of every plain LDS store
-      const unsigned pw0 = lds_addr(patch[0]) + frow * 256, pw1 = lds_addr(patch[1]) + frow * 256;
+      const unsigned pw[2] = {lds_addr(patch[0]) + frow * 256, lds_addr(patch[1]) + frow * 256};
+      // rotary epilogue (fused q|k|v projection): the lane's 8 columns sit at a fixed place c of a q or k head for the
+      // whole tile, only the position m mod S changes.  vmcnt retires in order, so a table load issued after a
+      // round's output stores would wait for those stores to be acknowledged: the tables of round r+1 are therefore
+      // requested BEFORE the stores of round r go out.
+      bool rot_on = false;
+      const float *tabA = nullptr, *tabB = nullptr;
+      if (ROT) {
+        const int sec = (int)(n / a.rot_D);
+        const int c = (int)((n - (int64_t)sec * a.rot_D) % a.rot_Dh);
+        rot_on = sec < 2 && c < a.rot_R;
+        tabA = (sec ? a.rot_ka : a.rot_qa) + c;
+        tabB = (sec ? a.rot_kb : a.rot_qb) + c;
+      }
+      f32x4 ta[2][2], tb[2][2];                        // [h][half]
+      auto load_tabs = [&](int i) {
+        if (ROT && rot_on) {
 #pragma unroll
-      for (int ip = 0; ip < 4; ++ip) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = ip * 2 + u;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            asm volatile("ds_write_b128 %0, %1" ::"v"((u ? pw1 : pw0) + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
+          for (int h = 0; h < 2; ++h) {
+            const int64_t m = m0 + wm * 128 + i * 16 + orow + 8 * h;
+            const int64_t o = (int64_t)(m % a.rot_S) * a.rot_R;
+            ta[h][0] = *reinterpret_cast<const f32x4*>(tabA + o);
+            ta[h][1] = *reinterpret_cast<const f32x4*>(tabA + o + 4);
+            tb[h][0] = *reinterpret_cast<const f32x4*>(tabB + o);
+            tb[h][1] = *reinterpret_cast<const f32x4*>(tabB + o + 4);
+          }
         }
-        f32x4 lo[2][2], hi[2][2];
+      };
+      load_tabs(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+      for (int i = 0; i < 8; ++i) {
+        const int u = i & 1;                           // alternate between the two free slots
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          asm volatile("ds_write_b128 %0, %1" ::"v"(pw[u] + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
+        if (!ROT) {
+          f32x4 lo[2], hi[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int r = orow + 8 * h;
             const unsigned base = lds_addr(patch[u]) + r * 256;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(lo[u][h]) : "v"(base + (((2 * oc) ^ r) << 4)) : "memory");
-            asm volatile("ds_read_b128 %0, %1" : "=v"(hi[u][h]) : "v"(base + (((2 * oc + 1) ^ r) << 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(lo[h]) : "v"(base + (((2 * oc) ^ r) << 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(hi[h]) : "v"(base + (((2 * oc + 1) ^ r) << 4)) : "memory");
           }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = ip * 2 + u;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int r = orow + 8 * h;
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[u][h][e] : hi[u][h][e - 4]) + bias[e];
+            for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[h][e] : hi[h][e - 4]) + bias[e];
             nt_store_row8(a, m0 + wm * 128 + i * 16 + r, n, v, true);
           }
+        } else {
+          // finish both rows, THEN ask for the next round's tables (into the same registers), THEN store
+          bf16x8 outv[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = orow + 8 * h;
+            const int64_t m = m0 + wm * 128 + i * 16 + r;
+            const unsigned base = lds_addr(patch[u]) + r * 256;
+            f32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(lo) : "v"(base + (((2 * oc) ^ r) << 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(hi) : "v"(base + (((2 * oc + 1) ^ r) << 4)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
+            if (a.preact) {
+              bf16x8 pz;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pz[e] = (bf16)v[e];
+              *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = pz;
+            }
+            if (rot_on) rot_apply8(v, ta[h][0], ta[h][1], tb[h][0], tb[h][1]);
+            outv[h] = nt_finish_row8(a, m, n, v);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < 8) load_tabs(i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<bf16x8*>(a.C + (m0 + wm * 128 + i * 16 + orow + 8 * h) * a.ldc + n) = outv[h];
         }
       }
     }
@@ -785,7 +862,8 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   static bool attr256_set = false;
   if (!attr256_set) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
     attr256_set = true;
   }
   if (a.M >= 1024 && a.N % 256 == 0) {              // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP)
@@ -796,7 +874,8 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
     if (stream_ok && a.M % B2 == 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
       const int ncu = meant_num_cus() & ~7;
       const int grid = (int)(ntm2 * ntn2 < ncu ? ((ntm2 * ntn2 + 7) / 8) * 8 : ncu);
-      hipLaunchKernelGGL(gemm_bf16_nt256s_kernel<0>, dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+      if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+      else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
     } else {
       hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
     }
