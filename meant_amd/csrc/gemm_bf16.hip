@@ -755,7 +755,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
   const int64_t mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
   if (mbeg >= mend) return;
   const int nt = (int)((mend - mbeg + TN_BKM - 1) / TN_BKM);
-  const bool do_bias = (dbias != nullptr) && (tk == 0) && (wk == 0);      // wave-uniform
+  // fused dbias: column sums of dY from the A fragments.  The conversions and adds are VALU work the MFMA stream has
+  // to wait for, so they are dealt out evenly: of the ntk workgroups that read the same dY tile, the one with
+  // tk == t mod ntk takes step t, and inside it wave wk takes k-sub-step ks == wk (everybody ends with atomics).
+  const bool do_bias = dbias != nullptr;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -785,6 +788,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
       tn256_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, nxt + TN2_TILE, wave + 4, lane);
     }
     const unsigned cbase = lds_addr(cur);
+    const bool bias_step = (t % ntk) == tk;
     // fragment reads are software-pipelined one k-step ahead: while the MFMAs of k-step ks run, the 12 transposed
     // reads of k-step ks+1 are in flight; the wait before the MFMAs is a counted lgkmcnt(12)
     u32x2 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
       for (int i = 0; i < 4; ++i) af[i] = pack_tr(alo[ks & 1][i], ahi[ks & 1][i]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) bfr[j] = pack_tr(blo[ks & 1][j], bhi[ks & 1][j]);
-      if (do_bias) {
+      if (do_bias && ks == wk && bias_step) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
