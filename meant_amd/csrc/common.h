@@ -108,6 +108,20 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// d/dx of the above with the same rational erfc; Phi and the density share one exponential
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);        // exp(-x^2 / 2)
+  const float half_erfc = 0.5f * p * t * e;
+  const float phi = x < 0.f ? half_erfc : 1.0f - half_erfc;
+  return fmaf(x * 0.39894228040143268f, e, phi);
+}
+
 // counter-based uniform in [0,1): splitmix-style hash of (seed, index); same value in fwd and bwd
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
@@ -115,6 +129,23 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
   return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+// Dropout keep-multipliers for 8 consecutive elements starting at element index `base` (a multiple of 8): one
+// 64-bit hash decides 4 elements, 16 bits each (keep iff the 16-bit draw >= p * 65536), so the price per element is a
+// quarter of a splitmix round.  The multiplier is 1 / (1 - p_q) for the quantised p_q the draws really implement.
+// Forward and backward call this with the same (seed, base) and get the same mask.
+__device__ __forceinline__ void keep_scale8(float p, uint64_t seed, uint64_t base, float (&m)[8]) {
+  const unsigned thr = (unsigned)(p * 65536.0f);
+  const float sc = 65536.0f / (float)(65536u - thr);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint64_t z = seed + ((base >> 2) + h) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[4 * h + q] = ((unsigned)(z >> (16 * q)) & 0xffffu) >= thr ? sc : 0.0f;
+  }
 }
 
 // ---- LDS helpers -------------------------------------------------------------------------------

@@ -13,10 +13,13 @@ namespace {
 constexpr int MAXC = 4;               // chunks of 8 per lane kept in registers -> d <= 2048
 constexpr int NORM_THREADS = 256;     // 4 waves = 4 rows in flight per block
 constexpr int NORM_MAX_BLOCKS = 1024;
+constexpr int NORM_PACKED_BLOCKS = 2048;
 
-__device__ __forceinline__ float keep_scale(float p, uint64_t seed, uint64_t idx) {
-  return hash_uniform(seed, idx) >= p ? 1.0f / (1.0f - p) : 0.0f;
-}
+// exact libm erf in the fp32 tier, the rational erfc (|error| 7.5e-8 in Phi) in the bf16 tier
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x);
+template <> __device__ __forceinline__ float gelu_grad_t<float>(float x) { return gelu_erf_grad(x); }
+template <> __device__ __forceinline__ float gelu_grad_t<bf16>(float x) { return gelu_erf_grad_fast(x); }
+
 
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
@@ -50,12 +53,10 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __re
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + ch * 8);
         const f32x4 g1 = *reinterpret_cast<const f32x4*>(scale + ch * 8 + 4);
         Vec8<T> o;
+        float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)row * d + ch * 8, km);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float val = (i < 4 ? g0[i] : g1[i - 4]) * (v[c].get(i) * r);
-          if (drop_p > 0.f) val *= keep_scale(drop_p, seed, (uint64_t)row * d + ch * 8 + i);
-          o.set(i, val);
-        }
+        for (int i = 0; i < 8; ++i) o.set(i, (i < 4 ? g0[i] : g1[i - 4]) * (v[c].get(i) * r) * km[i]);
         store8<T>(yr + ch * 8, o);
       }
     }
@@ -94,10 +95,11 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
         const Vec8<T> dv = load8<T>(dyr + ch * 8);
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + ch * 8);
         const f32x4 g1 = *reinterpret_cast<const f32x4*>(scale + ch * 8 + 4);
+        float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)row * d + ch * 8, km);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          float dyi = dv.get(i);
-          if (drop_p > 0.f) dyi *= keep_scale(drop_p, seed, (uint64_t)row * d + ch * 8 + i);
+          const float dyi = dv.get(i) * km[i];
           const float xi = xv[c].get(i);
           gacc[c][i] += dyi * xi * r;
           const float t = (i < 4 ? g0[i] : g1[i - 4]) * dyi;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
         if (gelu_pre) {                              // x = gelu(pre): chain through the activation in the same pass
           const Vec8<T> pv = load8<T>(gelu_pre + row * d + ch * 8);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o.set(i, o.get(i) * gelu_erf_grad(pv.get(i)));
+          for (int i = 0; i < 8; ++i) o.set(i, o.get(i) * gelu_grad_t<T>(pv.get(i)));
         }
         store8<T>(dxr + ch * 8, o);
       }
@@ -149,6 +151,170 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed-row variants for the widths the encoder uses.  One wave takes R consecutive rows as ONE flat run of
+// R * d / 8 chunks dealt lane-cyclically, C = R * d / 512 chunks per lane, every lane equally loaded
+// (d = 768: R = 2, C = 3 -- the generic kernel gives half the lanes two chunks and the other half one), all loads of
+// a row group issued before the first use, and twice the waves per CU in flight.
+template <typename T, int C>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                           T* __restrict__ y, float* __restrict__ rinv_out,
+                                                                           int64_t rows, int d, int R, float eps, float drop_p,
+                                                                           uint64_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  const float inv_sqrt_d = rsqrtf((float)d);
+  int rsel[C], col[C];                                 // which of the R rows / which column a lane's chunk c belongs to
+  f32x4 g0[C], g1[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = lane + 64 * c;
+    rsel[c] = k / nchunk;
+    col[c] = (k - rsel[c] * nchunk) * 8;
+    g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
+    g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+  }
+  const int64_t ngroups = rows / R;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = grp * R;
+    const T* xr = x + row0 * d;
+    Vec8<T> v[C];
+    float ss[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = load8<T>(xr + (lane + 64 * c) * 8);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      ss[c] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float f = v[c].get(i); ss[c] += f * f; }
+    }
+    float rr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) rr[c] = 0.f;
+    for (int r = 0; r < R; ++r) {                      // R <= 4 segmented sums
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) s += rsel[c] == r ? ss[c] : 0.f;
+      s = wave_sum(s);
+      const float rv = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+      if (lane == 0) rinv_out[row0 + r] = rv;
+#pragma unroll
+      for (int c = 0; c < C; ++c) rr[c] = rsel[c] == r ? rv : rr[c];
+    }
+    T* yr = y + row0 * d;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)(row0 + rsel[c]) * d + col[c], km);
+      Vec8<T> o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.set(i, (i < 4 ? g0[c][i] : g1[c][i - 4]) * (v[c].get(i) * rr[c]) * km[i]);
+      store8<T>(yr + (lane + 64 * c) * 8, o);
+    }
+  }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                           const float* __restrict__ scale,
+                                                                           const float* __restrict__ rinv, T* __restrict__ dx,
+                                                                           float* __restrict__ partial, int64_t rows, int d, int R,
+                                                                           float eps, float drop_p, uint64_t seed,
+                                                                           const T* __restrict__ dres, const T* __restrict__ gelu_pre) {
+  __shared__ float red[MAXC * 512];                    // per-block gain-gradient columns (d <= 2048)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  for (int j = threadIdx.x; j < d; j += NORM_THREADS) red[j] = 0.f;
+  int rsel[C], col[C];
+  f32x4 g0[C], g1[C];
+  float gacc[C][8];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = lane + 64 * c;
+    rsel[c] = k / nchunk;
+    col[c] = (k - rsel[c] * nchunk) * 8;
+    g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
+    g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
+  }
+  const int64_t ngroups = rows / R;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = grp * R;
+    const int64_t off = row0 * d;
+    Vec8<T> xv[C], dv[C], rv[C], pv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t o = off + (lane + 64 * c) * 8;
+      xv[c] = load8<T>(x + o);
+      dv[c] = load8<T>(dy + o);
+      if (dres) rv[c] = load8<T>(dres + o);
+      if (gelu_pre) pv[c] = load8<T>(gelu_pre + o);
+    }
+    float rr[C], cd[C], gd[C][8];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      rr[c] = rinv[row0 + rsel[c]];
+      float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)(row0 + rsel[c]) * d + col[c], km);
+      cd[c] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dyi = dv[c].get(i) * km[i];
+        const float xi = xv[c].get(i);
+        gacc[c][i] += dyi * xi * rr[c];
+        const float t = (i < 4 ? g0[c][i] : g1[c][i - 4]) * dyi;
+        gd[c][i] = t;
+        cd[c] += t * xi;
+      }
+    }
+    float kk[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) kk[c] = 0.f;
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) s += rsel[c] == r ? cd[c] : 0.f;
+      s = wave_sum(s);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (rsel[c] == r) {
+          const float nsd = (1.0f / rr[c] - eps) * (float)d;          // ||x|| * sqrt(d)
+          kk[c] = nsd > 0.f ? s * rr[c] * rr[c] / nsd : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      Vec8<T> o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float val = rr[c] * gd[c][i] - kk[c] * xv[c].get(i);
+        if (dres) val += rv[c].get(i);
+        if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
+        o.set(i, val);
+      }
+      store8<T>(dx + off + (lane + 64 * c) * 8, o);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&red[col[c] + i], gacc[c][i]);
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += NORM_THREADS) partial[(int64_t)blockIdx.x * d + j] = red[j];
+}
+
+// rows per wave R and chunks per lane C of the packed kernels, or R = 0 if the shape does not pack
+inline void norm_packing(int64_t rows, int64_t d, int& R, int& C) {
+  const int nchunk = (int)(d >> 3);
+  for (R = 1; R <= 4; R *= 2) {
+    if ((R * nchunk) % 64 == 0 && R * nchunk / 64 <= 3 && rows % R == 0) { C = R * nchunk / 64; return; }
+  }
+  R = 0; C = 0;
 }
 
 // out[j] = sum_p partial[p, j]   (and optionally a second array at partial + np*d)
@@ -276,6 +442,10 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_bwd_kernel(const T* __
   }
 }
 
+inline int packed_blocks(int64_t groups) {
+  int64_t b = ceil_div(groups, 4);
+  return (int)(b < 1 ? 1 : (b > NORM_PACKED_BLOCKS ? NORM_PACKED_BLOCKS : b));
+}
 inline int norm_blocks(int64_t rows) {
   int64_t b = ceil_div(rows, 4);
   return (int)(b < 1 ? 1 : (b > NORM_MAX_BLOCKS ? NORM_MAX_BLOCKS : b));
@@ -291,6 +461,18 @@ extern "C" int meant_rmsnorm_fwd(const void* x, const float* scale, void* y, flo
   MEANT_REQUIRE(meant_aligned16(x) && meant_aligned16(y) && meant_aligned16(scale), MEANT_ERR_ARG, "rmsnorm_fwd: 16-byte alignment");
   MEANT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MEANT_ERR_ARG, "rmsnorm_fwd: drop_p out of range");
   if (rows == 0) return MEANT_OK;
+  int R, C;
+  norm_packing(rows, d, R, C);
+  if (R) {
+    const int nb = packed_blocks(rows / R);
+#define LAUNCH_FWD(CC)                                                                                                        \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_fwd_packed_kernel<T, CC>), dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+                                                (const T*)x, scale, (T*)y, rinv, rows, (int)d, R, eps, drop_p, seed))
+    if (C == 1) LAUNCH_FWD(1); else if (C == 2) LAUNCH_FWD(2); else LAUNCH_FWD(3);
+#undef LAUNCH_FWD
+    MEANT_LAUNCH_CHECK("rmsnorm_fwd");
+    return MEANT_OK;
+  }
   DISPATCH_DTYPE(dtype, T,
                  hipLaunchKernelGGL(rmsnorm_fwd_kernel<T>, dim3(norm_blocks(rows)), dim3(NORM_THREADS), 0, (hipStream_t)stream,
                                     (const T*)x, scale, (T*)y, rinv, rows, (int)d, eps, drop_p, seed));
@@ -298,7 +480,10 @@ extern "C" int meant_rmsnorm_fwd(const void* x, const float* scale, void* y, flo
   return MEANT_OK;
 }
 
-extern "C" size_t meant_rmsnorm_bwd_ws(int64_t rows, int64_t d) { return (size_t)norm_blocks(rows) * d * sizeof(float) * 2; }
+extern "C" size_t meant_rmsnorm_bwd_ws(int64_t rows, int64_t d) {
+  const int64_t nb = norm_blocks(rows) > packed_blocks(rows) ? norm_blocks(rows) : packed_blocks(rows);
+  return (size_t)nb * d * sizeof(float) * 2;
+}
 
 extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx,
                                  float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed,
@@ -307,6 +492,19 @@ extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* sca
   MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd: null pointer");
   MEANT_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd: unsupported d=%lld", (long long)d);
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd: workspace too small");
+  int R, C;
+  norm_packing(rows, d, R, C);
+  if (R) {
+    const int nbp = packed_blocks(rows / R);
+#define LAUNCH_BWD(CC)                                                                                                        \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+                                                (const T*)dy, (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, R, eps,    \
+                                                drop_p, seed, (const T*)dres, (const T*)gelu_pre))
+    if (C == 1) LAUNCH_BWD(1); else if (C == 2) LAUNCH_BWD(2); else LAUNCH_BWD(3);
+#undef LAUNCH_BWD
+    MEANT_LAUNCH_CHECK("rmsnorm_bwd");
+    return colsum_launch(workspace, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
+  }
   const int nb = norm_blocks(rows);
   DISPATCH_DTYPE(dtype, T,
                  hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
