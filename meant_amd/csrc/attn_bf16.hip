@@ -50,17 +50,29 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
 }
 
 // stage a [64 rows][64 cols] bf16 tile: rows row0.. (clamped to nrows-1) of a matrix with row stride ld.
-// 8 pieces of 1 KiB (8 rows each); wave w issues pieces 2w, 2w+1.
-__device__ __forceinline__ void stage64(const bf16* __restrict__ g, int64_t ld, int row0, int nrows, char* tile, int wave, int lane) {
+// 8 pieces of 1 KiB (8 rows each); wave w issues pieces 2w, 2w+1.  A lane's row-in-tile and swizzled 16-byte column
+// never change, so its two element offsets are computed once (StageOff); per tile only the uniform tile origin moves.
+// Rows past the end of the sequence exist only in a ragged last tile, which gets its own clamped pair.
+struct StageOff { unsigned full[2], last[2]; };
+__device__ __forceinline__ StageOff make_stage_off(int64_t ld, int nrows, int wave, int lane) {
+  StageOff o;
+  const int last0 = ((nrows - 1) / KV_TILE) * KV_TILE;              // first row of the last tile
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int piece = wave * 2 + i;
-    const int r = piece * 8 + (lane >> 3);
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ swz(r);
-    int gr = row0 + r;
-    gr = gr < nrows ? gr : nrows - 1;
-    glds16(g + (int64_t)gr * ld + c * 8, tile + piece * 1024);
+    const int rl = last0 + r < nrows ? r : nrows - 1 - last0;
+    o.full[i] = (unsigned)(r * ld + c * 8);
+    o.last[i] = (unsigned)(rl * ld + c * 8);
   }
+  return o;
+}
+__device__ __forceinline__ void stage64(const bf16* __restrict__ g, int64_t ld, int row0, int nrows, char* tile, int wave, int lane,
+                                        const StageOff& so) {
+  const bf16* origin = g + (int64_t)row0 * ld;                       // uniform
+  const bool ragged = row0 + KV_TILE > nrows;                        // uniform
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(origin + (ragged ? so.last[i] : so.full[i]), tile + (wave * 2 + i) * 1024);
 }
 
 // A/B fragment of mfma_32x32x16 from a row-major tile: lane (r = lane&31, h = lane>>5) gets
@@ -227,7 +239,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   int kend = S;                                      // keys needed by this block
   if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
   int nt = (kend + KV_TILE - 1) / KV_TILE;
-  while (nt > 1 && (flg[nt - 1] & 2)) --nt;          // trailing all-padding tiles contribute exactly 0
+  // The per-tile flags are fetched ONCE, into two wave-uniform 64-bit masks.  (A flag load inside the tile loop sits
+  // behind the DMA just issued for the next tile in the in-order vmcnt queue: waiting for the flag would drain the
+  // DMA and serialise every tile's load with its math.)
+  uint64_t special_mask = 0, skip_mask = 0;
+  const bool masks_ok = ntile <= 64;
+  if (masks_ok) {
+    const int f = lane < ntile ? flg[lane] : 0;
+    special_mask = __ballot(f & 1);
+    skip_mask = __ballot(f & 2);
+  }
+  auto tile_flag = [&](int t) -> int {
+    return masks_ok ? (int)((special_mask >> t) & 1) | ((int)((skip_mask >> t) & 1) << 1) : flg[t];
+  };
+  while (nt > 1 && (tile_flag(nt - 1) & 2)) --nt;    // trailing all-padding tiles contribute exactly 0
 
   f32x16 oacc[2];
 #pragma unroll
@@ -238,9 +263,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   const float c1 = a.scale * LOG2E;
 
   // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
+  const StageOff soff = make_stage_off(ld, S, wave, lane);
   auto stage = [&](int t, int buf) {
-    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
-    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
+    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
     if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   const TrOff troff = make_troff(lane);
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const int k0 = t * KV_TILE;
-    const int flag = flg[t];
+    const int flag = tile_flag(t);
     const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));   // wave-uniform: tile not entirely above the diagonal / all padding
     if (active && q0 < S) {
       const char* Kt = smem + buf * 2 * TILE_B;
@@ -272,15 +298,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);   // tile touches the diagonal for some query of this wave
       const bool special = diag || (flag & 1);
       float tmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (!special) {
+      if (!special) {                                  // raw scores: the scale is folded into the exponent below
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float t = sacc[sb][e] * c1;
-            sacc[sb][e] = t;
-            tmx[e & 3] = fmaxf(tmx[e & 3], t);
-          }
+          for (int e = 0; e < 16; ++e) tmx[e & 3] = fmaxf(tmx[e & 3], sacc[sb][e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmx[e] *= c1;
       } else {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
@@ -311,11 +335,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
           for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
       }
       float ps[4] = {0.f, 0.f, 0.f, 0.f};
+      const float ec = special ? 1.0f : c1;            // special tiles hold scaled + biased scores already
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float p = __builtin_amdgcn_exp2f(sacc[sb][e] - m_run);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[sb][e], ec, -m_run));
           sacc[sb][e] = p;
           ps[e & 3] += p;
         }
@@ -418,7 +443,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   int kend = S;
   if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
   int nt = (kend + KV_TILE - 1) / KV_TILE;
-  while (nt > 1 && (flg[nt - 1] & 2)) --nt;          // trailing all-padding tiles contribute exactly 0
+  // The per-tile flags are fetched ONCE, into two wave-uniform 64-bit masks.  (A flag load inside the tile loop sits
+  // behind the DMA just issued for the next tile in the in-order vmcnt queue: waiting for the flag would drain the
+  // DMA and serialise every tile's load with its math.)
+  uint64_t special_mask = 0, skip_mask = 0;
+  const bool masks_ok = ntile <= 64;
+  if (masks_ok) {
+    const int f = lane < ntile ? flg[lane] : 0;
+    special_mask = __ballot(f & 1);
+    skip_mask = __ballot(f & 2);
+  }
+  auto tile_flag = [&](int t) -> int {
+    return masks_ok ? (int)((special_mask >> t) & 1) | ((int)((skip_mask >> t) & 1) << 1) : flg[t];
+  };
+  while (nt > 1 && (tile_flag(nt - 1) & 2)) --nt;    // trailing all-padding tiles contribute exactly 0
 
   f32x16 dqacc[2];
 #pragma unroll
@@ -427,9 +465,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     for (int e = 0; e < 16; ++e) dqacc[b][e] = 0.f;
 
   // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
+  const StageOff soff = make_stage_off(ld, S, wave, lane);
   auto stage = [&](int t, int buf) {
-    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane);
-    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
+    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
     if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   const TrOff troff = make_troff(lane);
@@ -440,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const int k0 = t * KV_TILE;
-    const int flag = flg[t];
+    const int flag = tile_flag(t);
     const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));
     if (active && q0 < S) {
       const char* Kt = smem + buf * 2 * TILE_B;
@@ -553,9 +592,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
   const int t0 = block_dead ? nt : (a.causal ? kb0 / 64 : 0);   // first query tile that can see this block's keys
 
   // per-tile statistics by DMA too: st[0..127] = interleaved (m, log l) pairs of the 64 queries, st[128..191] = delta
+  const StageOff soff_q = make_stage_off(ld, S, wave, lane), soff_do = make_stage_off(D, S, wave, lane);
   auto stage = [&](int t, int buf) {
-    stage64(base, ld, t * 64, S, smem + buf * 2 * TILE_B, wave, lane);
-    stage64(dO, D, t * 64, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+    stage64(base, ld, t * 64, S, smem + buf * 2 * TILE_B, wave, lane, soff_q);
+    stage64(dO, D, t * 64, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff_do);
     if (wave == 0) {
       float* st = stats + buf * 192;
       const int last = 2 * S - 1;
