@@ -12,7 +12,7 @@ def per_dispatch(d, counter):
     f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
     vals = []
     for r in csv.DictReader(open(f)):
-        if "gemm_bf16_nt256_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "gemm_bf16_nt256s_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     vals.sort()
     return [v for _, v in vals]
@@ -26,7 +26,7 @@ for i, (M, N, K) in enumerate(SHAPES):
     alg = (M * K + N * K + M * N) * 2
     res[f"{M},{N},{K}"] = {"hbm_bytes": f + w, "fetch_bytes_corrected": f, "write_bytes": w, "algorithmic_bytes": alg,
                            "ratio": round((f + w) / alg, 3)}
-json.dump({"kernel": "gemm_bf16_nt256_kernel", "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
+json.dump({"kernel": "gemm_bf16_nt256s_kernel", "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
            "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)", "shapes": res},
           open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
