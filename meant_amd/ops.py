@@ -202,10 +202,13 @@ class _LinearPre(torch.autograd.Function):
         N = weight.shape[0]
         yv, pv = y.view(*shp[:-1], N), pre.view(*shp[:-1], N)
         ctx.mark_non_differentiable(yv)
+        ctx.set_materialize_grads(False)     # no zero tensor for the non-differentiable output in backward
         return yv, pv
 
     @staticmethod
     def backward(ctx, _dy_unused, dpre):
+        if dpre is None:
+            return None, None, None
         (x2,) = ctx.saved_tensors
         N = ctx.weight.shape[0]
         d2 = _c(dpre).view(-1, N)
