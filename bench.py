@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity-mode numerics)")
     ap.add_argument("--two-streams", type=int, default=-1, help="override meant_amd.modules.TWO_STREAMS (0/1)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time the step with clip + fused AdamW (extra field)")
+    ap.add_argument("--from-host", choices=["f64", "f32", "u8"], default=None,
+                    help="also time the step fed by meant_amd.data.DeviceBatchLoader from host arrays of this pixel type "
+                         "(PCIe-inclusive secondary figure, never `value`)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -292,6 +295,45 @@ def main():
         barrier()
         opt_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
+    # secondary figure: the same step fed from HOST arrays in the data set's storage type through the double-buffered
+    # loader (gather into pinned memory, H2D on its own stream, conversion + normalisation + patchify on the device)
+    host_ms = None
+    if args.from_host is not None:
+        from meant_amd.data import DeviceBatchLoader
+        nbatch = 3 + args.steps
+        npdt = {"f64": np.float64, "f32": np.float32, "u8": np.uint8}[args.from_host]
+        rs = np.random.RandomState(7 + rank)
+        pool = 2 * B                                      # two batches' worth of distinct samples, visited repeatedly
+        if npdt == np.uint8:
+            h_graphs = rs.randint(0, 256, (pool, L, C, IMG, IMG)).astype(np.uint8)
+        else:
+            h_graphs = rs.standard_normal((pool, L, C, IMG, IMG)).astype(npdt)
+        h_tweets = rs.randint(0, V, (pool, L, S)).astype(np.int64)
+        h_masks = np.ones((pool, L, S), dtype=np.float32)
+        h_labels = rs.randint(0, NCLS, (pool,)).astype(np.int64)
+        if npdt == np.uint8:
+            model.patchEmbed[0].set_normalization(127.5, 73.9)
+        loader = DeviceBatchLoader(h_graphs, h_tweets, None, h_masks, h_labels, batch_size=B, device=dev)
+
+        def host_steps(n):
+            done = 0
+            while done < n:
+                for g_, tw_, _, am_, y_ in loader:
+                    reducer.prepare()
+                    loss_ = cross_entropy_on_probs(model(tw_, g_, am_), y_)
+                    loss_.backward()
+                    reducer.wait()
+                    done += 1
+                    if done >= n:
+                        break
+        host_steps(2)
+        barrier()
+        t2 = time.perf_counter()
+        host_steps(args.steps)
+        barrier()
+        host_ms = (time.perf_counter() - t2) / args.steps * 1e3
+        model.patchEmbed[0].set_normalization(0.0, 1.0)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         sps = world * B * args.steps / elapsed
@@ -321,6 +363,13 @@ def main():
         if opt_ms is not None:
             res["with_optimizer"] = {"ms_per_step": round(opt_ms, 3), "samples_per_s": round(world * B / opt_ms * 1e3, 2),
                                      "what": "fwd+CE+bwd + global-norm clip(1.0) + fused AdamW on the flat fp32 buckets"}
+        if host_ms is not None:
+            bytes_per_sample = L * C * IMG * IMG * {"f64": 8, "f32": 4, "u8": 1}[args.from_host] + L * S * 12 + 8
+            res["from_host"] = {"pixels": args.from_host, "ms_per_step": round(host_ms, 3),
+                                "samples_per_s": round(world * B / host_ms * 1e3, 2),
+                                "h2d_GB_per_s_per_gpu": round(B * bytes_per_sample / host_ms / 1e6, 2),
+                                "what": "same step, batches gathered from host numpy arrays into pinned staging, H2D on a side "
+                                        "stream (double-buffered), pixel conversion + patchify on the device"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(E)
         print(json.dumps(res), flush=True)

@@ -29,6 +29,9 @@ extern "C" {
 #endif
 
 enum meant_dtype { MEANT_F32 = 0, MEANT_BF16 = 1 };
+/* storage-only types of raw inputs (meant_patchify_raw): the reference keeps its price graphs as float64 .npy
+ * (in_loop_train.py:48,589); uint8 is what a rendered chart is before anyone converts it */
+enum meant_raw_dtype { MEANT_RAW_F32 = 0, MEANT_RAW_BF16 = 1, MEANT_RAW_F64 = 2, MEANT_RAW_U8 = 3 };
 
 enum meant_status {
   MEANT_OK = 0,
@@ -148,6 +151,12 @@ int meant_temporal_attn_bwd(const void* q, const void* kv, const float* p, const
  * images: float or act [G, C, Hh, Ww] -> patches act [G*(Hh/p)*(Ww/p), p*p*C], channel fastest. */
 int meant_patchify(const void* images, int images_dtype, void* patches, int64_t G, int C, int Hh, int Ww, int p,
                    int dtype, void* stream);
+
+/* ---- input pipeline: raw pixels -> normalised patches in one pass ----- in_loop_train.py:48,589-602 (float64
+ * graphs, optional global (x - mean) / std), meant/meant.py:194 (patchify).
+ * images: raw [G, C, Hh, Ww] of meant_raw_dtype; patches act [G*(Hh/p)*(Ww/p), p*p*C] = ((float)x - mean) * inv_std. */
+int meant_patchify_raw(const void* images, int raw_dtype, float mean, float inv_std, void* patches, int64_t G, int C,
+                       int Hh, int Ww, int p, int dtype, void* stream);
 
 /* ---- sequence mean-pool ------------------------------------------- meant/meant.py:231
  * x: act [G, S, d] -> out[g, col_off : col_off+d] of a [G, ld_out] buffer (the concat) whose storage type

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmeant_hip.so")
 
 F32, BF16 = 0, 1
+RAW_F32, RAW_BF16, RAW_F64, RAW_U8 = 0, 1, 2, 3      # meant_raw_dtype (input pipeline)
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SIGMOID = 0, 1, 2, 4
 
 _p, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -38,6 +39,7 @@ SIGNATURES = {
     "meant_temporal_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
     "meant_temporal_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
     "meant_patchify": (_i, [_p, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "meant_patchify_raw": (_i, [_p, _i, _f, _f, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "meant_meanpool_fwd": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i, _p]),
     "meant_meanpool_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _p]),
     "meant_add_rowvec": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),

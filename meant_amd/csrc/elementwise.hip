@@ -180,6 +180,31 @@ __global__ __launch_bounds__(EW_THREADS) void patchify_c4_kernel(const TI* __res
   }
 }
 
+// raw-input variant (the device side of the input pipeline): any storage type in, affine normalisation in fp32, the
+// compute dtype out.  One thread = one pixel position of a patch row: it reads the C channel values (coalesced along
+// the row inside each channel plane) and writes C consecutive outputs.
+__device__ __forceinline__ float raw_to_f(double v) { return (float)v; }
+__device__ __forceinline__ float raw_to_f(float v) { return v; }
+__device__ __forceinline__ float raw_to_f(bf16 v) { return (float)v; }
+__device__ __forceinline__ float raw_to_f(unsigned char v) { return (float)v; }
+template <typename TI, typename T>
+__global__ __launch_bounds__(EW_THREADS) void patchify_raw_kernel(const TI* __restrict__ img, T* __restrict__ out, int64_t G, int C,
+                                                                   int Hh, int Ww, int p, float mean, float inv_std) {
+  const int nph = Hh / p, npw = Ww / p;
+  const int64_t total = G * (int64_t)Hh * Ww;        // pixel positions, ordered (g, ph, pw, p1, p2) = output order / C
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / (p * p);
+    const int e = (int)(i - r * (p * p));
+    const int p2 = e % p, p1 = e / p;
+    const int pw = (int)(r % npw); r /= npw;
+    const int ph = (int)(r % nph);
+    const int64_t g = r / nph;
+    const int64_t pix = (int64_t)(ph * p + p1) * Ww + pw * p + p2;
+    T* o = out + i * C;
+    for (int c = 0; c < C; ++c) o[c] = from_f<T>((raw_to_f(img[(g * C + c) * (int64_t)Hh * Ww + pix]) - mean) * inv_std);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K8 mean over the sequence axis.  block = (g, 256-column slab): 32 chunks x 8 row groups.
 template <typename T, typename TO>
@@ -468,6 +493,30 @@ extern "C" int meant_rotary_qk(void* qkv, int64_t T_rows, int64_t S, int H, int 
     else hipLaunchKernelGGL((rotary_kernel<T, false>), dim3(ew_blocks(items)), dim3(EW_THREADS), 0, (hipStream_t)stream, (T*)qkv, T_rows, (int)S, H, Dh, R, qa, qb, ka, kb);
   });
   MEANT_LAUNCH_CHECK("rotary_qk");
+  return MEANT_OK;
+}
+
+extern "C" int meant_patchify_raw(const void* images, int raw_dtype, float mean, float inv_std, void* patches, int64_t G, int C,
+                                  int Hh, int Ww, int p, int dtype, void* stream) {
+  EW_REQ(images && patches && G > 0 && C > 0 && p > 0 && Hh % p == 0 && Ww % p == 0, "patchify_raw: bad argument");
+  EW_REQ(dtype == MEANT_F32 || dtype == MEANT_BF16, "patchify_raw: unknown output dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = G * (int64_t)Hh * Ww;
+  const dim3 grid((unsigned)(ceil_div(total, EW_THREADS) < 65535 * 16 ? ceil_div(total, EW_THREADS) : 65535 * 16)), block(EW_THREADS);
+#define RAW_LAUNCH(TI)                                                                                                          \
+  do {                                                                                                                          \
+    if (dtype == MEANT_F32) hipLaunchKernelGGL((patchify_raw_kernel<TI, float>), grid, block, 0, st, (const TI*)images, (float*)patches, G, C, Hh, Ww, p, mean, inv_std); \
+    else hipLaunchKernelGGL((patchify_raw_kernel<TI, bf16>), grid, block, 0, st, (const TI*)images, (bf16*)patches, G, C, Hh, Ww, p, mean, inv_std); \
+  } while (0)
+  switch (raw_dtype) {
+    case MEANT_RAW_F32: RAW_LAUNCH(float); break;
+    case MEANT_RAW_BF16: RAW_LAUNCH(bf16); break;
+    case MEANT_RAW_F64: RAW_LAUNCH(double); break;
+    case MEANT_RAW_U8: RAW_LAUNCH(unsigned char); break;
+    default: meant_set_error("patchify_raw: unknown raw dtype %d", raw_dtype); return MEANT_ERR_ARG;
+  }
+#undef RAW_LAUNCH
+  MEANT_LAUNCH_CHECK("patchify_raw");
   return MEANT_OK;
 }
 

@@ -321,15 +321,21 @@ class temporalEncoder(nn.Module):
 
 class _Patchify(nn.Module):
     """einops Rearrange('b c (h p1) (w p2) -> b (h w) (p1 p2 c)') of meant/meant.py:194, emitting the
-    compute dtype.  Parameter-free, sits at index 0 so the Linear keeps the key `patchEmbed.1.*`."""
+    compute dtype.  Parameter-free, sits at index 0 so the Linear keeps the key `patchEmbed.1.*`.
+    Accepts raw float64 / uint8 / float32 / bf16 pixels; `set_normalization(mean, std)` folds the data set's global
+    (x - mean) / std (in_loop_train.py:591-593) into the same pass (not part of the state_dict, like the reference's)."""
 
     def __init__(self, p):
         super().__init__()
         self.p = p
         self.out_dtype = torch.float32
+        self.norm_mean, self.norm_std = 0.0, 1.0
+
+    def set_normalization(self, mean: float, std: float):
+        self.norm_mean, self.norm_std = float(mean), float(std)
 
     def forward(self, images):
-        return ops.patchify(images, self.p, self.out_dtype)
+        return ops.patchify(images, self.p, self.out_dtype, self.norm_mean, self.norm_std)
 
 
 class _PatchEmbed(nn.Sequential):

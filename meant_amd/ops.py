@@ -572,17 +572,28 @@ def add_rowvec(x, v):
     return _AddRowVec.apply(x, v)
 
 
-def patchify(images, p: int, dtype: torch.dtype):
-    """einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (meant/meant.py:194); no gradient to pixels."""
+_RAW_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 2, torch.uint8: 3}
+
+
+def patchify(images, p: int, dtype: torch.dtype, mean: float = 0.0, std: float = 1.0):
+    """einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (meant/meant.py:194); no gradient to pixels.
+
+    `images` may be in any storage type the reference's data path produces (float64 .npy graphs,
+    in_loop_train.py:48,589; uint8 renderings; float32; bf16): the conversion, the optional global
+    normalisation (x - mean) / std of in_loop_train.py:591-593 and the patch layout are one pass on the device."""
     _need_gpu(images)
-    if images.dtype not in (torch.float32, torch.bfloat16):
+    if images.dtype not in _RAW_DTYPES:
         images = images.float()
     images = _c(images)
     G, Cc, Hh, Ww = images.shape
     n = (Hh // p) * (Ww // p)
     out = torch.empty((G, n, p * p * Cc), device=images.device, dtype=dtype)
-    check(lib.meant_patchify(_p(images), _dt(images), _p(out), G, Cc, Hh, Ww, p, F32 if dtype == torch.float32 else BF16,
-                             _stream()), "patchify")
+    odt = F32 if dtype == torch.float32 else BF16
+    if images.dtype in (torch.float32, torch.bfloat16) and mean == 0.0 and std == 1.0:
+        check(lib.meant_patchify(_p(images), _dt(images), _p(out), G, Cc, Hh, Ww, p, odt, _stream()), "patchify")
+    else:
+        check(lib.meant_patchify_raw(_p(images), _RAW_DTYPES[images.dtype], float(mean), 1.0 / float(std), _p(out), G, Cc, Hh, Ww, p,
+                                     odt, _stream()), "patchify_raw")
     return out
 
 

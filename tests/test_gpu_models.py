@@ -197,3 +197,35 @@ def test_autocast_selects_bf16_and_state_dict_roundtrip(dev):
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert torch.equal(m3(ids, img, mask), o32)
+
+
+@pytest.mark.gpu
+def test_model_on_device_batch_loader_float64(dev):
+    """the reference's data path end to end (in_loop_train.py:579-639 -> :202-217): float64 graphs on the host,
+    global normalisation, batches through the double-buffered loader, forward under autocast; must equal the forward
+    on tensors prepared by hand"""
+    import numpy as np
+    import meant_amd as M
+    from meant_amd.data import DeviceBatchLoader, global_mean_std
+    rs = np.random.RandomState(11)
+    n, L, S = 6, 3, 16
+    graphs = rs.standard_normal((n, L, 4, 32, 32)) * 2 + 0.5
+    tweets = rs.randint(0, 100, (n, L, S))
+    masks = np.ones((n, L, S), dtype=np.float32)
+    masks[1, :, 12:] = 0
+    labels = rs.randint(0, 2, (n,))
+    torch.manual_seed(0)
+    model = M.meant(128, 128, 4, 32, 32, 16, L, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=1, channels=4).to(dev).eval()
+    mean, std = global_mean_std(graphs)
+    model.patchEmbed[0].set_normalization(mean, std)
+    loader = DeviceBatchLoader(graphs, tweets, None, masks, labels, batch_size=2, device=dev)
+    outs = []
+    for g, tw, _, am, y in loader:
+        assert g.dtype == torch.float64 and g.is_cuda
+        outs.append(model(tw.long(), g, am).float().cpu())
+    got = torch.cat(outs)
+    model.patchEmbed[0].set_normalization(0.0, 1.0)
+    gn = torch.from_numpy(((graphs - mean) / std).astype("float32")).to(dev)
+    ref = model(torch.from_numpy(tweets).to(dev), gn, torch.from_numpy(masks).to(dev)).float().cpu()
+    assert got.shape == (n, 2)
+    assert (got - ref).abs().max().item() < 2e-5

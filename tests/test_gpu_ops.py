@@ -341,6 +341,29 @@ def test_meanpool_patchify_embedding_rowvec(M, O, dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("raw", ["f64", "f32", "u8"])
+def test_patchify_raw_inputs(M, O, dev, dtype, raw):
+    """input pipeline: float64 / float32 / uint8 pixels + the data set's global (x - mean) / std
+    become patches in one device pass; oracle = normalise on the host in float64 as in_loop_train.py:591-593 does,
+    then the oracle's patchify"""
+    from meant_amd import ops
+    rs = np.random.RandomState(5)
+    if raw == "u8":
+        img = rs.randint(0, 256, (3, 4, 32, 48)).astype("uint8")
+    else:
+        img = (rs.standard_normal((3, 4, 32, 48)) * 3 + 1).astype("float64" if raw == "f64" else "float32")
+    mean, std = float(img.astype("float64").mean()), float(img.astype("float64").std())
+    ref = O.patchify(t(((img.astype("float64") - mean) / std).astype("float32")), 16)
+    got = ops.patchify(torch.from_numpy(img).to(dev), 16, dtype, mean, std)
+    assert got.dtype == dtype and got.shape == ref.shape
+    assert_close(got, ref, 1e-5 if dtype == torch.float32 else 2e-2, "patchify_raw")
+    # C != 4 and no normalisation
+    img3 = rs.standard_normal((2, 3, 16, 16))
+    got3 = ops.patchify(torch.from_numpy(img3).to(dev), 8, dtype)
+    assert_close(got3, O.patchify(t(img3.astype("float32")), 8), 1e-6 if dtype == torch.float32 else 2e-2, "patchify_raw c3")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_embedding_backward_sorted_path(M, dev, dtype):
     """large token counts take the sorted scatter-add: heavy duplication (a padding-like hot id) must sum exactly"""
     from meant_amd import ops

@@ -79,3 +79,26 @@ def test_shard_batch():
     assert shard_batch(1024, 3, 8) == (384, 512)
     with pytest.raises(AssertionError):
         shard_batch(10, 0, 4)
+
+
+def test_device_batch_loader_cpu_matches_slicing():
+    """the input pipeline's host logic: batches equal plain slicing of the host arrays in the shared
+    permutation, `None` members stay None, ranks partition every global batch, mean/std are the global ones"""
+    import numpy as np
+    from meant_amd.data import DeviceBatchLoader, global_mean_std, shard_indices
+    rs = np.random.RandomState(0)
+    g = rs.standard_normal((20, 2, 4, 8, 8))
+    t = rs.randint(0, 100, (20, 2, 16))
+    m = np.ones((20, 2, 16), dtype=np.float32)
+    y = rs.randint(0, 2, (20,))
+    ld = DeviceBatchLoader(g, t, None, m, y, batch_size=4, device="cpu", shuffle=True, seed=3)
+    idx = shard_indices(20, 0, 1, 4, True, 3, 0)
+    assert len(ld) == 5
+    for b, (gg, tt, mm, am, yy) in enumerate(ld):
+        sel = idx[b * 4:(b + 1) * 4]
+        assert mm is None and gg.dtype == torch.float64
+        assert np.array_equal(gg.numpy(), g[sel]) and np.array_equal(tt.numpy(), t[sel]) and np.array_equal(yy.numpy(), y[sel])
+    i0, i1 = shard_indices(20, 0, 2, 4, True, 3, 0), shard_indices(20, 1, 2, 4, True, 3, 0)
+    assert len(set(i0) & set(i1)) == 0 and len(i0) == len(i1) == 8
+    mean, std = global_mean_std(g)
+    assert abs(mean - g.mean()) < 1e-12 and abs(std - g.std()) < 1e-12
