@@ -200,6 +200,15 @@ int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorted_ids, cons
  * loss (caller zeroes it), dprobs (optional) receives d loss / d probs. */
 int meant_ce_probs(const float* probs, const int64_t* target, float* loss_accum, float* dprobs, int64_t B, int C,
                    void* stream);
+/* ---- large-vocabulary softmax cross-entropy (MLM pretrainer) ----------- pretrain_mlm.py:160,178
+ * nn.CrossEntropyLoss() on logits act [T, ld] (V <= ld valid columns, the rest padding of the vocabulary GEMM),
+ * target int64 [T] with `ignore_index` rows skipped.  fwd: row_loss[t] = logsumexp - logit[target] (0 if ignored),
+ * lse[t] saved.  bwd: dlogits[t, j] = (softmax_j - [j == target]) * gscale[0] for j < V, 0 for ignored rows and for
+ * the padding columns; gscale is a device scalar (d loss / n_valid), dlogits may alias logits. */
+int meant_softmax_ce_fwd(const void* logits, int64_t ld, const int64_t* target, int64_t T, int64_t V, int64_t ignore_index,
+                         float* row_loss, float* lse, int dtype, void* stream);
+int meant_softmax_ce_bwd(const void* logits, int64_t ld, const int64_t* target, const float* lse, int64_t T, int64_t V,
+                         int64_t ignore_index, const float* gscale, void* dlogits, int dtype, void* stream);
 /* out_accum[0] += sum(x^2) over a flat float buffer (global gradient norm; caller zeroes the scalar) */
 int meant_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream);
 /* One AdamW step (torch.optim.AdamW semantics, `step` >= 1 for the bias corrections) over flat float buffers.

@@ -9,9 +9,9 @@ from .modules import (  # noqa: F401
     RMSNorm, LayerNorm, Linear, RotaryEmbedding,
     attention, xPosAttention, temporal, flash_attention, xPosAttention_flash,
     visionEncoder, languageEncoder, temporalEncoder,
-    meant, meant_vision, meant_tweet, meant_vqa,
+    meant, meant_vision, meant_tweet, meant_vqa, meant_language_pretrainer,
 )
 
-from . import parallel, train  # noqa: F401,E402
+from . import parallel, train, data  # noqa: F401,E402
 
 __version__ = "0.1.0"

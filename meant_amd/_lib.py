@@ -52,6 +52,8 @@ SIGNATURES = {
     "meant_embedding_fwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "meant_embedding_bwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "meant_ce_probs": (_i, [_p, _p, _p, _p, _i64, _i, _p]),
+    "meant_softmax_ce_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _i, _p]),
+    "meant_softmax_ce_bwd": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _p, _i, _p]),
     "meant_sumsq_f32": (_i, [_p, _i64, _p, _p]),
     "meant_adamw_f32": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _f, _f, _p]),
     "meant_embedding_bwd_sorted": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),

@@ -81,6 +81,87 @@ __global__ void ce_probs_kernel(const float* __restrict__ x, const int64_t* __re
   if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Softmax cross-entropy over a large vocabulary (the MLM pretrainer's loss, pretrain_mlm.py:160,178:
+// nn.CrossEntropyLoss() on logits [T, V = 64001] with ignore_index = -100).  One workgroup per row, the row is read
+// ONCE in the forward (online max / sum-exp in the log2 domain) and once more in the backward, which writes
+// d logits = (softmax - onehot) * g in the activation dtype (zeros for ignored rows and for the padding columns
+// V..ld-1 that the padded vocabulary GEMM carries).  HBM-bound: 2 B per logit forward, 4 B per logit backward.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
+                                                             int V, int64_t ignore_index, float* __restrict__ row_loss,
+                                                             float* __restrict__ lse_out) {
+  __shared__ float red_m[4], red_s[4];
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  const int tid = threadIdx.x;
+  float m = -INFINITY, s = 0.f;                        // running max (natural units) and sum of exp(x - m)
+  const int nchunk = V >> 3;
+  for (int c = tid; c < nchunk; c += 256) {
+    const Vec8<T> v = load8<T>(x + c * 8);
+    float cm = v.get(0);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v.get(i));
+    const float mn = fmaxf(m, cm);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += __expf(v.get(i) - mn);
+    s = s * __expf(m - mn) + acc;
+    m = mn;
+  }
+  for (int j = (nchunk << 3) + tid; j < V; j += 256) {   // ragged tail (V = 64001)
+    const float xv = to_f(x[j]);
+    const float mn = fmaxf(m, xv);
+    s = s * __expf(m - mn) + __expf(xv - mn);
+    m = mn;
+  }
+  // combine (m, s) pairs across the wave, then across the 4 waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, mo);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mn));
+    m = mn;
+  }
+  if ((tid & 63) == 0) { red_m[tid >> 6] = m; red_s[tid >> 6] = s; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])), Ssum = 0.f;
+    for (int w = 0; w < 4; ++w) Ssum += red_m[w] == -INFINITY ? 0.f : red_s[w] * __expf(red_m[w] - M);
+    const float lse = M + __logf(Ssum);
+    lse_out[row] = lse;
+    const int64_t t = target[row];
+    row_loss[row] = (t == ignore_index || t < 0 || t >= V) ? 0.f : lse - to_f(x[t]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
+                                                             const float* __restrict__ lse, int V, int64_t ignore_index,
+                                                             const float* __restrict__ gscale, T* __restrict__ dlogits) {
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  T* dx = dlogits + row * ld;
+  const int tid = threadIdx.x;
+  const int64_t t = target[row];
+  const bool ignored = (t == ignore_index || t < 0 || t >= V);
+  const float g = ignored ? 0.f : gscale[0];
+  const float l = lse[row];
+  const int nchunk_ld = (int)(ld >> 3);                // ld % 8 == 0 (checked by the launcher): covers the padding too
+  for (int c = tid; c < nchunk_ld; c += 256) {
+    const Vec8<T> v = load8<T>(x + c * 8);
+    Vec8<T> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = c * 8 + i;
+      float d = (j < V && !ignored) ? __expf(v.get(i) - l) : 0.f;
+      if (j == t) d -= 1.f;
+      o.set(i, d * g);
+    }
+    store8<T>(dx + c * 8, o);
+  }
+}
+
 }  // namespace
 
 extern "C" int meant_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream) {
@@ -111,5 +192,29 @@ extern "C" int meant_ce_probs(const float* probs, const int64_t* target, float* 
   MEANT_REQUIRE(probs && target && loss_accum && B > 0 && C > 0, MEANT_ERR_ARG, "ce_probs: bad argument");
   hipLaunchKernelGGL(ce_probs_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, (hipStream_t)stream, probs, target, loss_accum, dprobs, B, C);
   MEANT_LAUNCH_CHECK("ce_probs");
+  return MEANT_OK;
+}
+
+extern "C" int meant_softmax_ce_fwd(const void* logits, int64_t ld, const int64_t* target, int64_t T, int64_t V, int64_t ignore_index,
+                                    float* row_loss, float* lse, int dtype, void* stream) {
+  MEANT_REQUIRE(logits && target && row_loss && lse, MEANT_ERR_ARG, "softmax_ce_fwd: null pointer");
+  MEANT_REQUIRE(T >= 0 && V > 0 && V < (1LL << 31) && ld >= V && ld % 8 == 0 && meant_aligned16(logits), MEANT_ERR_ARG,
+                "softmax_ce_fwd: need 0 < V <= ld, ld %% 8 == 0, 16-byte aligned logits");
+  if (T == 0) return MEANT_OK;
+  DISPATCH_DTYPE(dtype, Tt, hipLaunchKernelGGL(softmax_ce_fwd_kernel<Tt>, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream,
+                                               (const Tt*)logits, ld, target, (int)V, ignore_index, row_loss, lse));
+  MEANT_LAUNCH_CHECK("softmax_ce_fwd");
+  return MEANT_OK;
+}
+
+extern "C" int meant_softmax_ce_bwd(const void* logits, int64_t ld, const int64_t* target, const float* lse, int64_t T, int64_t V,
+                                    int64_t ignore_index, const float* gscale, void* dlogits, int dtype, void* stream) {
+  MEANT_REQUIRE(logits && target && lse && gscale && dlogits, MEANT_ERR_ARG, "softmax_ce_bwd: null pointer");
+  MEANT_REQUIRE(T >= 0 && V > 0 && V < (1LL << 31) && ld >= V && ld % 8 == 0 && meant_aligned16(logits) && meant_aligned16(dlogits),
+                MEANT_ERR_ARG, "softmax_ce_bwd: need 0 < V <= ld, ld %% 8 == 0, 16-byte aligned buffers");
+  if (T == 0) return MEANT_OK;
+  DISPATCH_DTYPE(dtype, Tt, hipLaunchKernelGGL(softmax_ce_bwd_kernel<Tt>, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream,
+                                               (const Tt*)logits, ld, target, lse, (int)V, ignore_index, gscale, (Tt*)dlogits));
+  MEANT_LAUNCH_CHECK("softmax_ce_bwd");
   return MEANT_OK;
 }

@@ -515,3 +515,52 @@ class meant_vqa(nn.Module):
 # single backend: the reference's flash variants are aliases (meant/flash_attention.py, meant/xPosAttention_flash.py)
 flash_attention = attention
 xPosAttention_flash = xPosAttention
+
+
+# ------------------------------------------------------------------------------------------
+def _is_roberta_lm_head(h) -> bool:
+    """HF `RobertaLMHead`: dense -> gelu -> layer_norm -> decoder (weight usually tied to the word embedding)"""
+    return all(hasattr(h, a) for a in ("dense", "layer_norm", "decoder")) and isinstance(getattr(h, "decoder"), nn.Linear)
+
+
+class meant_language_pretrainer(nn.Module):
+    """pretrain_mlm.py:74-88: masked-language-model pretrainer around `num_encoders` languageEncoders.
+    `embedding` and `lm_head` are the caller's modules (the reference passes HF `RobertaForMaskedLM(...).roberta.
+    embeddings` and `.lm_head`, :318-319) and keep their own parameter names, so `state_dict` keys match the
+    reference's (`embedding.0.*`, `languageEncoders.i.*`, `mlm_head.*`).  A head with RobertaLMHead's structure
+    runs on the HIP path (GELU in the GEMM epilogue, LayerNorm kernel, padded vocabulary GEMM); any other head is
+    called as is.  `forward` returns the logits like the reference; `loss(...)` is forward + CrossEntropyLoss
+    (pretrain_mlm.py:160,178) with the logits kept in the padded buffer of the vocabulary GEMM end to end."""
+
+    def __init__(self, num_encoders, mlm_input_dim, embedding, lm_head, flash=False, lag=5, text_dim=768, num_heads=8):
+        super().__init__()
+        self.embedding = nn.ModuleList([embedding])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads, flash=flash) for _ in range(num_encoders)])
+        self.mlm_head = lm_head
+        self.lag = lag
+
+    def _encode(self, words, attention_mask):
+        dt = resolve_compute_dtype(self, None)
+        x = _embed(self.embedding, words, dt)
+        for enc in self.languageEncoders:
+            x = enc(x, attention_mask=attention_mask)
+        return x
+
+    def _head_features(self, x):
+        h = self.mlm_head
+        y = ops.linear(x, h.dense.weight, h.dense.bias, None, EPI_GELU)
+        return ops.layernorm(y, h.layer_norm.weight, h.layer_norm.bias, h.layer_norm.eps)
+
+    def forward(self, words, attention_mask):
+        x = self._encode(words, attention_mask)
+        h = self.mlm_head
+        if _is_roberta_lm_head(h):
+            return ops.vocab_linear(self._head_features(x), h.decoder.weight, h.decoder.bias)
+        return h(x)
+
+    def loss(self, words, attention_mask, labels, ignore_index: int = -100):
+        x = self._encode(words, attention_mask)
+        h = self.mlm_head
+        if _is_roberta_lm_head(h):
+            return ops.vocab_linear_cross_entropy(self._head_features(x), h.decoder.weight, h.decoder.bias, labels, ignore_index)
+        return ops.softmax_cross_entropy(h(x), labels, ignore_index)

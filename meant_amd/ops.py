@@ -644,3 +644,76 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     out = torch.empty_like(x, dtype=dtype)
     check(lib.meant_cast(_p(x), _dt(x), _p(out), F32 if dtype == torch.float32 else BF16, x.numel(), _stream()), "cast")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# MLM pretrainer (pretrain_mlm.py:74-88, :160, :178)
+VOCAB_PAD = 256        # the vocabulary GEMM runs on N rounded up to the 256-wide tile of the streaming kernel
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(logits[:, :V], target) with ignore_index (default -100), mean over the rows that count,
+    on a row-padded logits buffer [T, ld >= V]: one pass over the logits forward, one backward, no [T, V] fp32
+    log-softmax tensor.  The gradient is returned for the whole padded buffer (zeros in the padding)."""
+
+    @staticmethod
+    def forward(ctx, logits_pad, target, V, ignore_index):
+        _need_gpu(logits_pad, target)
+        logits_pad = _c(logits_pad)
+        T, ld = logits_pad.shape
+        assert ld % 8 == 0 and V <= ld
+        tgt = _c(target.long())
+        row_loss = torch.empty(T, device=logits_pad.device, dtype=torch.float32)
+        lse = torch.empty(T, device=logits_pad.device, dtype=torch.float32)
+        check(lib.meant_softmax_ce_fwd(_p(logits_pad), ld, _p(tgt), T, V, int(ignore_index), _p(row_loss), _p(lse), _dt(logits_pad),
+                                       _stream()), "softmax_ce_fwd")
+        nvalid = ((tgt != ignore_index) & (tgt >= 0) & (tgt < V)).sum().clamp_(min=1).float()
+        ctx.save_for_backward(logits_pad, tgt, lse, nvalid)
+        ctx.V, ctx.ignore_index = int(V), int(ignore_index)
+        return row_loss.sum() / nvalid
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits_pad, tgt, lse, nvalid = ctx.saved_tensors
+        T, ld = logits_pad.shape
+        g = (dloss.float() / nvalid).reshape(1).contiguous()
+        dl = torch.empty_like(logits_pad)
+        check(lib.meant_softmax_ce_bwd(_p(logits_pad), ld, _p(tgt), _p(lse), T, ctx.V, ctx.ignore_index, _p(g), _p(dl), _dt(logits_pad),
+                                       _stream()), "softmax_ce_bwd")
+        return dl, None, None, None
+
+
+def _vocab_logits_padded(x, weight, bias):
+    V, d = weight.shape
+    Vp = (V + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD
+    wp = torch.nn.functional.pad(weight, (0, 0, 0, Vp - V)) if Vp != V else weight
+    bp = None
+    if bias is not None:
+        bp = torch.nn.functional.pad(bias, (0, Vp - V)) if Vp != V else bias
+    return linear(x, wp, bp)                           # [..., Vp]
+
+
+def vocab_linear(x, weight, bias=None):
+    """logits = x W^T + b for a big (tied) vocabulary matrix W [V, d] (pretrain_mlm.py:88 -> RobertaLMHead.decoder).
+    Returns a [..., V] VIEW of a buffer whose rows are padded to a multiple of 256 columns, so that the GEMM takes
+    the streaming 256 x 256 kernel.  The padding rows of W are zeros appended by a differentiable op: gradients come
+    back for exactly the V real rows."""
+    return _vocab_logits_padded(x, weight, bias)[..., :weight.shape[0]]
+
+
+def vocab_linear_cross_entropy(x, weight, bias, target, ignore_index: int = -100):
+    """CrossEntropyLoss(vocab_linear(x).view(-1, V), target.view(-1)) without ever slicing or re-homing the logits:
+    the padded logits buffer goes straight into the fused loss and its gradient straight back into the GEMMs."""
+    lp = _vocab_logits_padded(x, weight, bias)
+    return _SoftmaxCE.apply(lp.reshape(-1, lp.shape[-1]), target.reshape(-1), weight.shape[0], ignore_index)
+
+
+def softmax_cross_entropy(logits, target, ignore_index: int = -100):
+    """mean CE over the last axis of `logits` ([..., V], any leading shape, any strides) against integer targets.
+    Rows are re-homed once into a buffer with an 8-element-aligned stride when they are not already laid out so."""
+    V = logits.shape[-1]
+    l2 = logits.reshape(-1, V)
+    Vp = (V + 7) // 8 * 8
+    if Vp != V or not l2.is_contiguous():
+        l2 = torch.nn.functional.pad(l2, (0, Vp - V))
+    return _SoftmaxCE.apply(l2, target.reshape(-1), V, ignore_index)

@@ -231,5 +231,45 @@ def main():
     model_case("meant_full_c3", m, dict(tweets=ids, images=img, mask=mask), np.array([0, 1]), store_inputs=False)
 
 
+def gen_mlm(R):
+    """MLM pretrainer KAT: the reference's own class from pretrain_mlm.py, imported with its plotting /
+    logging dependencies stubbed, 2 encoder layers, d=128, 2 heads (Dh=64), V=120, S=24"""
+    import types
+    from oracle.meant_oracle import fill_weights_, mlm_parts
+    sys.modules.pop("flash_attn", None)      # the stub has served the reference's imports; transformers probes the real name
+    tb = types.ModuleType("torch.utils.tensorboard"); tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    sys.modules["meant"].languageEncoder = R.meant.languageEncoder          # `from meant import languageEncoder` (:44)
+    sys.modules["utils"].mlm_dataset = object                               # `from utils import mlm_dataset` (:45)
+    ref = _load("_ref_pretrain_mlm", f"{REF}/pretrain_mlm.py")
+    torch.manual_seed(0)
+    emb, head = mlm_parts()
+    m = ref.meant_language_pretrainer(2, 128, emb, head, text_dim=128, num_heads=2).eval()
+    fill_weights_(m, 2468)
+    r = np.random.RandomState(104)
+    ids = r.randint(2, 120, (3, 24)).astype("int64")
+    mask = np.ones((3, 24), dtype="float32"); mask[1, 18:] = 0; mask[2, 9:] = 0
+    labels = np.full((3, 24), -100, dtype="int64")
+    pick = r.rand(3, 24) < 0.25
+    labels[pick] = r.randint(2, 120, int(pick.sum()))
+    out = m(torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+    loss = torch.nn.CrossEntropyLoss()(out.view(-1, 120), torch.from_numpy(labels).view(-1))     # pretrain_mlm.py:160,178
+    loss.backward()
+    names, norms = grads_of(m)
+    params = dict(m.named_parameters())
+    arrs = dict(ids=ids, mask=mask, labels=labels, logits=_np(out), loss=np.array(loss.item(), dtype="float64"),
+                grad_names=np.array(names), grad_norms=norms)
+    for k in ["mlm_head.dense.weight", "mlm_head.bias", "mlm_head.layer_norm.weight", "languageEncoders.1.encode.2.q.weight",
+              "embedding.0.word_embeddings.weight", "embedding.0.LayerNorm.bias"]:
+        g = params[k].grad
+        arrs["grad__" + k] = _np(g if g.numel() <= 4096 else g[:4])
+    save("mlm_pretrainer_tiny", **arrs)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mlm":
+        torch.set_num_threads(8)
+        gen_mlm(load_reference())
+    else:
+        main()
+        gen_mlm(load_reference())

@@ -445,6 +445,40 @@ class meant_vqa(nn.Module):
 # deterministic weights / inputs shared by gen_golden.py, the tests and bench.py
 # (SURVEY.md section 8c "fixture recipe": numpy RandomState only, no torch RNG)
 # --------------------------------------------------------------------------------------
+class meant_language_pretrainer(nn.Module):
+    """pretrain_mlm.py:74-88 -- the MLM pretrainer: a caller-supplied embedding module (the reference passes HF
+    `RobertaForMaskedLM(...).roberta.embeddings`, :318), `num_encoders` languageEncoders (default num_heads = 8) and a
+    caller-supplied vocabulary head (HF `lm_head`, :319); returns the head's logits.  `mlm_input_dim` and `lag` are
+    accepted and unused, as in the reference.  The loss is nn.CrossEntropyLoss() over logits.view(-1, V) with the
+    -100 labels ignored (:160,178)."""
+
+    def __init__(self, num_encoders, mlm_input_dim, embedding, lm_head, flash=False, lag=5, text_dim=768, num_heads=8):
+        super().__init__()
+        self.embedding = nn.ModuleList([embedding])
+        self.languageEncoders = nn.ModuleList([languageEncoder(text_dim, num_heads) for _ in range(num_encoders)])
+        self.mlm_head = lm_head
+        self.lag = lag
+
+    def forward(self, words, attention_mask):
+        for mod in self.embedding:
+            words = mod(words)
+        for enc in self.languageEncoders:
+            words = enc(words, attention_mask=attention_mask)
+        return self.mlm_head(words)
+
+
+def mlm_parts(vocab=120, hidden=128, max_pos=40):
+    """the embedding module and vocabulary head the reference's MLM driver hands to its pretrainer
+    (pretrain_mlm.py:297-319: RobertaForMaskedLM._from_config -> .roberta.embeddings / .lm_head), tiny config"""
+    from transformers import RobertaConfig, RobertaForMaskedLM
+    cfg = RobertaConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=1, num_attention_heads=2, intermediate_size=2 * hidden,
+                        max_position_embeddings=max_pos, pad_token_id=1, type_vocab_size=1, layer_norm_eps=1e-5,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    rob = RobertaForMaskedLM._from_config(cfg)
+    return rob.roberta.embeddings, rob.lm_head
+
+
+
 def fill_weights_(model: nn.Module, seed: int = 1234) -> nn.Module:
     import numpy as np
     rs = np.random.RandomState(seed)

@@ -229,3 +229,64 @@ def test_model_on_device_batch_loader_float64(dev):
     ref = model(torch.from_numpy(tweets).to(dev), gn, torch.from_numpy(masks).to(dev)).float().cpu()
     assert got.shape == (n, 2)
     assert (got - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_mlm_pretrainer_golden(dev, golden, dtype):
+    """pretrain_mlm.py:74-88 + CrossEntropyLoss(:160) against the reference's own class (fixture), both
+    through forward() + the fused loss on the returned logits view and through loss() (padded logits end to end)"""
+    import meant_amd as M
+    from oracle import meant_oracle as O
+    g = golden("mlm_pretrainer_tiny")
+    ids, mask, labels = (torch.from_numpy(g[k]).to(dev) for k in ("ids", "mask", "labels"))
+    tol_out, tol_loss, tol_g = (2e-4, 2e-5, 2e-3) if dtype == torch.float32 else (6e-2, 2e-2, 6e-2)
+    for mode in ("forward", "loss"):
+        torch.manual_seed(0)
+        emb, head = O.mlm_parts()
+        m = M.meant_language_pretrainer(2, 128, emb, head, text_dim=128, num_heads=2)
+        O.fill_weights_(m, 2468)
+        m = m.to(dev).eval()
+        m.compute_dtype = dtype
+        if mode == "forward":
+            out = m(ids, attention_mask=mask)
+            assert out.shape == (3, 24, 120)
+            assert (out.float().cpu() - torch.from_numpy(g["logits"])).abs().max().item() < tol_out * max(1.0, float(np.abs(g["logits"]).max()))
+            loss = M.ops.softmax_cross_entropy(out, labels)
+        else:
+            loss = m.loss(ids, mask, labels)
+        assert abs(loss.item() - float(g["loss"])) < tol_loss * max(1.0, float(g["loss"])), (mode, loss.item(), float(g["loss"]))
+        loss.backward()
+        params = dict(m.named_parameters())
+        floor = 1e-3 * float(np.max(g["grad_norms"]))
+        for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+            got = params[str(nm)].grad.double().norm().item()
+            assert abs(got - refn) <= tol_g * max(refn, floor), (mode, str(nm), got, refn)
+        for k in g.files:
+            if k.startswith("grad__"):
+                p_ = params[k[6:]]
+                ref = torch.from_numpy(g[k])
+                got = (p_.grad if p_.grad.numel() <= 4096 else p_.grad[:4]).float().cpu()
+                assert (got - ref).abs().max().item() <= tol_g * max(ref.abs().max().item(), floor), (mode, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_softmax_cross_entropy_large_vocab(dev, dtype):
+    """the fused loss at the real vocabulary width (V = 64001, ragged: not a multiple of 8), ignored rows, padding
+    columns: loss and d logits against torch on the same (rounded) logits"""
+    import meant_amd as M
+    T, V = 37, 64001
+    gen = torch.Generator().manual_seed(3)
+    logits = (torch.randn(T, V, generator=gen) * 3).to(dtype)
+    target = torch.randint(0, V, (T,), generator=gen)
+    target[::5] = -100
+    ref_in = logits.float().clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, target)
+    ref.backward()
+    x = logits.to(dev).requires_grad_()
+    loss = M.ops.softmax_cross_entropy(x, target.to(dev))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < (1e-5 if dtype == torch.float32 else 2e-3) * ref.item()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2 * ref_in.grad.abs().max().item()
+    assert (x.grad.float().cpu() - ref_in.grad).abs().max().item() <= max(tol, 1e-7)

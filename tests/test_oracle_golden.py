@@ -172,3 +172,22 @@ def test_meant_full_c3(golden):
     m = O.meant(768, 768, 4, 224, 224, 16, 12, 2, torch.nn.Embedding(2000, 768), num_heads=12, num_encoders=1)
     _check_model(g, m, (ids, img, mask), grad_rtol=1e-3)
     np.testing.assert_allclose(g["out"], [[0.713732, 0.527026], [0.701181, 0.410244]], atol=1e-6)
+
+
+def test_mlm_pretrainer_tiny(golden):
+    """the oracle's restatement of pretrain_mlm.py:74-88 against the reference's own class (HF Roberta
+    embeddings + lm_head around two languageEncoders), logits / CE over V with -100 ignored / gradients"""
+    g = golden("mlm_pretrainer_tiny")
+    torch.manual_seed(0)
+    emb, head = O.mlm_parts()
+    m = O.meant_language_pretrainer(2, 128, emb, head, text_dim=128, num_heads=2).eval()
+    O.fill_weights_(m, 2468)
+    out = m(torch.from_numpy(g["ids"]), attention_mask=torch.from_numpy(g["mask"]))
+    loss = torch.nn.functional.cross_entropy(out.view(-1, 120), torch.from_numpy(g["labels"]).view(-1))
+    loss.backward()
+    assert (out.detach() - torch.from_numpy(g["logits"])).abs().max().item() < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    params = dict(m.named_parameters())
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        got = params[str(nm)].grad.double().norm().item()
+        assert abs(got - refn) <= 1e-4 * max(refn, 1e-6), (nm, got, refn)
