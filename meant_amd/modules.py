@@ -564,3 +564,45 @@ class meant_language_pretrainer(nn.Module):
         if _is_roberta_lm_head(h):
             return ops.vocab_linear_cross_entropy(self._head_features(x), h.decoder.weight, h.decoder.bias, labels, ignore_index)
         return ops.softmax_cross_entropy(h(x), labels, ignore_index)
+
+
+# ------------------------------------------------------------------------------------------
+def _is_vit_mim_decoder(dec) -> bool:
+    """HF ViTForMaskedImageModeling.decoder: Sequential(Conv2d(hidden, stride^2 * C_out, kernel 1), PixelShuffle(stride))"""
+    return (isinstance(dec, nn.Sequential) and len(dec) == 2 and isinstance(dec[0], nn.Conv2d) and dec[0].kernel_size == (1, 1)
+            and dec[0].stride == (1, 1) and dec[0].groups == 1 and isinstance(dec[1], nn.PixelShuffle))
+
+
+class meant_vision_pretrainer(nn.Module):
+    """pretrain_mim.py:77-99: masked-image-modelling pretrainer.  patchify + Linear, ONE visionEncoder
+    (`num_encoders` is ignored, as in the reference, :86), then the caller's decoder on the (B, d, sqrt(n), sqrt(n))
+    feature map.  `state_dict` keys: `patchEmbed.1.*`, `visionEncoders.0.*`, `decoder.*` (the caller's module, kept as
+    is).  When the decoder is HF's ViT masked-image-modelling decoder -- a 1x1 convolution followed by PixelShuffle --
+    the convolution runs as the per-token GEMM it is (weight [stride^2 C, d, 1, 1] viewed as [stride^2 C, d]) on the
+    HIP path and the pixel shuffle is a view/permute of its output; any other decoder is called as is."""
+
+    def __init__(self, num_encoders, decoder, mlm_input_dim, patch_res=16, channels=4, height=224, width=224, image_dim=768, num_heads=8):
+        super().__init__()
+        self.channels = channels
+        self.patch_dim = channels * patch_res * patch_res
+        self.n = int((height * width) / (patch_res ** 2))
+        self.patchEmbed = _PatchEmbed(self.patch_dim, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads, flash=True)])
+        self.decoder = decoder
+
+    def forward(self, images):
+        dt = resolve_compute_dtype(self, images)
+        x = self.patchEmbed(images, dt)                                  # [B, n, d]
+        for enc in self.visionEncoders:
+            x = enc(x)
+        b, n, c = x.shape
+        hw = math.floor(n ** 0.5)
+        dec = self.decoder
+        if _is_vit_mim_decoder(dec):
+            conv, r = dec[0], dec[1].upscale_factor
+            y = ops.linear(x, conv.weight.view(conv.out_channels, c), conv.bias)          # [B, n, r*r*C_out], token-major
+            co = conv.out_channels // (r * r)
+            # PixelShuffle: out[b, co, h*r + i, w*r + j] = y[b, (h, w), co*r*r + i*r + j]
+            y = y.view(b, hw, hw, co, r, r).permute(0, 3, 1, 4, 2, 5).reshape(b, co, hw * r, hw * r)
+            return y
+        return dec(x.permute(0, 2, 1).reshape(b, c, hw, hw))

@@ -266,10 +266,44 @@ def gen_mlm(R):
     save("mlm_pretrainer_tiny", **arrs)
 
 
+def gen_mim(R):
+    """MIM pretrainer KAT: the reference's own class from pretrain_mim.py, d=128, 2 heads, 32x32 images
+    with 4 channels, HF ViTForMaskedImageModeling decoder (1x1 conv + PixelShuffle) with stride 16"""
+    import types
+    from oracle.meant_oracle import fill_weights_, mim_decoder
+    sys.modules.pop("flash_attn", None)
+    tb = types.ModuleType("torch.utils.tensorboard"); tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    sys.modules["meant"].visionEncoder = R.meant.visionEncoder
+    sys.modules["meant"].languageEncoder = R.meant.languageEncoder
+    sys.modules["utils"].mlm_dataset = object
+    sys.modules["utils"].mim_dataset = object
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))                  # data-set I/O only (pretrain_mim.py:48)
+    ref = _load("_ref_pretrain_mim", f"{REF}/pretrain_mim.py")
+    torch.manual_seed(0)
+    m = ref.meant_vision_pretrainer(1, mim_decoder(), 128, patch_res=16, channels=4, height=32, width=32, image_dim=128, num_heads=2).eval()
+    fill_weights_(m, 1357)
+    r = np.random.RandomState(105)
+    img = r.standard_normal((3, 4, 32, 32)).astype("float32")
+    tgt = r.standard_normal((3, 4, 32, 32)).astype("float32")
+    out = m(torch.from_numpy(img))
+    loss = torch.nn.L1Loss()(out, torch.from_numpy(tgt)[:, 0:3])                 # pretrain_mim.py:162,204
+    loss.backward()
+    names, norms = grads_of(m)
+    params = dict(m.named_parameters())
+    arrs = dict(images=img, target=tgt, out=_np(out), loss=np.array(loss.item(), dtype="float64"), grad_names=np.array(names), grad_norms=norms)
+    for k in ["decoder.0.bias", "visionEncoders.0.encode.2.q.weight", "patchEmbed.1.bias"]:
+        g = params[k].grad
+        arrs["grad__" + k] = _np(g if g.numel() <= 4096 else g[:4])
+    save("mim_pretrainer_tiny", **arrs)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mlm":
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
         torch.set_num_threads(8)
-        gen_mlm(load_reference())
+        {"mlm": gen_mlm, "mim": gen_mim}[sys.argv[2]](load_reference())
     else:
         main()
-        gen_mlm(load_reference())
+        R_ = load_reference()
+        gen_mlm(R_)
+        gen_mim(R_)

@@ -467,6 +467,38 @@ class meant_language_pretrainer(nn.Module):
         return self.mlm_head(words)
 
 
+class meant_vision_pretrainer(nn.Module):
+    """pretrain_mim.py:77-99 -- masked-image-modelling pretrainer: patchify + Linear, ONE visionEncoder (the
+    reference ignores `num_encoders`, :86), tokens reshaped to a (B, d, sqrt(n), sqrt(n)) feature map (:95-98) and a
+    caller-supplied decoder (the reference passes HF `ViTForMaskedImageModeling(...).decoder`, :338-339: 1x1 conv to
+    stride^2 * 3 channels + PixelShuffle).  Loss: nn.L1Loss() against the first 3 channels of the target image (:162,204)."""
+
+    def __init__(self, num_encoders, decoder, mlm_input_dim, patch_res=16, channels=4, height=224, width=224, image_dim=768, num_heads=8):
+        super().__init__()
+        self.channels = channels
+        self.patch_dim = channels * patch_res * patch_res
+        self.n = int((height * width) / (patch_res ** 2))
+        self.patchEmbed = _PatchEmbed(self.patch_dim, image_dim, patch_res)
+        self.visionEncoders = nn.ModuleList([visionEncoder(image_dim, num_heads)])
+        self.decoder = decoder
+
+    def forward(self, images):
+        x = self.patchEmbed(images)
+        for enc in self.visionEncoders:
+            x = enc(x)
+        b, n, c = x.shape
+        hw = math.floor(n ** 0.5)
+        return self.decoder(x.permute(0, 2, 1).reshape(b, c, hw, hw))
+
+
+def mim_decoder(hidden=128, stride=16, image=32):
+    """the decoder the reference's MIM driver takes from HF ViTForMaskedImageModeling (pretrain_mim.py:338), tiny config"""
+    from transformers import ViTConfig, ViTForMaskedImageModeling
+    cfg = ViTConfig(hidden_size=hidden, num_hidden_layers=1, num_attention_heads=2, intermediate_size=2 * hidden, image_size=image,
+                    patch_size=stride, num_channels=3, encoder_stride=stride)
+    return ViTForMaskedImageModeling._from_config(cfg).decoder
+
+
 def mlm_parts(vocab=120, hidden=128, max_pos=40):
     """the embedding module and vocabulary head the reference's MLM driver hands to its pretrainer
     (pretrain_mlm.py:297-319: RobertaForMaskedLM._from_config -> .roberta.embeddings / .lm_head), tiny config"""

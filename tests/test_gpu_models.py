@@ -290,3 +290,31 @@ def test_softmax_cross_entropy_large_vocab(dev, dtype):
     assert abs(loss.item() - ref.item()) < (1e-5 if dtype == torch.float32 else 2e-3) * ref.item()
     tol = 1e-6 if dtype == torch.float32 else 2e-2 * ref_in.grad.abs().max().item()
     assert (x.grad.float().cpu() - ref_in.grad).abs().max().item() <= max(tol, 1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_mim_pretrainer_golden(dev, golden, dtype):
+    """pretrain_mim.py:77-99 + L1Loss (:162) against the reference's own class (fixture); the HF ViT
+    decoder's 1x1 convolution runs as a GEMM on the HIP path"""
+    import meant_amd as M
+    from oracle import meant_oracle as O
+    g = golden("mim_pretrainer_tiny")
+    torch.manual_seed(0)
+    m = M.meant_vision_pretrainer(1, O.mim_decoder(), 128, patch_res=16, channels=4, height=32, width=32, image_dim=128, num_heads=2)
+    O.fill_weights_(m, 1357)
+    m = m.to(dev).eval()
+    m.compute_dtype = dtype
+    out = m(torch.from_numpy(g["images"]).to(dev))
+    assert out.shape == (3, 3, 32, 32)
+    scale = float(np.abs(g["out"]).max())
+    assert (out.float().cpu() - torch.from_numpy(g["out"])).abs().max().item() < (2e-5 if dtype == torch.float32 else 3e-2) * scale
+    loss = torch.nn.functional.l1_loss(out.float(), torch.from_numpy(g["target"]).to(dev)[:, 0:3])
+    assert abs(loss.item() - float(g["loss"])) < (1e-5 if dtype == torch.float32 else 1e-2) * float(g["loss"])
+    loss.backward()
+    params = dict(m.named_parameters())
+    tol_g = 2e-3 if dtype == torch.float32 else 6e-2
+    floor = 1e-3 * float(np.max(g["grad_norms"]))
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        got = params[str(nm)].grad.double().norm().item()
+        assert abs(got - refn) <= tol_g * max(refn, floor), (str(nm), got, refn)

@@ -191,3 +191,21 @@ def test_mlm_pretrainer_tiny(golden):
     for nm, refn in zip(g["grad_names"], g["grad_norms"]):
         got = params[str(nm)].grad.double().norm().item()
         assert abs(got - refn) <= 1e-4 * max(refn, 1e-6), (nm, got, refn)
+
+
+def test_mim_pretrainer_tiny(golden):
+    """the oracle's restatement of pretrain_mim.py:77-99 against the reference's own class (patch embed,
+    one visionEncoder, HF ViT masked-image-modelling decoder), output / L1 loss on the first 3 channels / gradients"""
+    g = golden("mim_pretrainer_tiny")
+    torch.manual_seed(0)
+    m = O.meant_vision_pretrainer(1, O.mim_decoder(), 128, patch_res=16, channels=4, height=32, width=32, image_dim=128, num_heads=2).eval()
+    O.fill_weights_(m, 1357)
+    out = m(torch.from_numpy(g["images"]))
+    loss = torch.nn.functional.l1_loss(out, torch.from_numpy(g["target"])[:, 0:3])
+    loss.backward()
+    assert (out.detach() - torch.from_numpy(g["out"])).abs().max().item() < 5e-6 * float(np.abs(g["out"]).max())   # outputs are O(30)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    params = dict(m.named_parameters())
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        got = params[str(nm)].grad.double().norm().item()
+        assert abs(got - refn) <= 1e-4 * max(refn, 1e-6), (nm, got, refn)
