@@ -177,6 +177,10 @@ int meant_add_rowvec_bwd(const void* dy, float* dv, int64_t rows, int64_t d, int
 int meant_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
 /* dx = dy * y * (1-y) */
 int meant_sigmoid_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+/* GEGLU ---------------------------------------------------- src/meant/timesformer_pytorch.py:60-63
+ * h: act [rows, 2w] = [a | g]  ->  y: act [rows, w] = a * gelu(g);   dh = [dy * gelu(g) | dy * a * gelu'(g)] */
+int meant_geglu_fwd(const void* h, void* y, int64_t rows, int64_t w, int dtype, void* stream);
+int meant_geglu_bwd(const void* h, const void* dy, void* dh, int64_t rows, int64_t w, int dtype, void* stream);
 /* y = a + b */
 int meant_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 /* dst(act dtype_dst) = src(dtype_src), n elements */

@@ -9,7 +9,7 @@ from .modules import (  # noqa: F401
     RMSNorm, LayerNorm, Linear, RotaryEmbedding,
     attention, xPosAttention, temporal, flash_attention, xPosAttention_flash,
     visionEncoder, languageEncoder, temporalEncoder,
-    meant, meant_vision, meant_tweet, meant_vqa, meant_language_pretrainer, meant_vision_pretrainer,
+    meant, meant_vision, meant_tweet, meant_vqa, meant_language_pretrainer, meant_vision_pretrainer, TimeSformer,
 )
 
 from . import parallel, train, data  # noqa: F401,E402

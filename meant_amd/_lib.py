@@ -46,6 +46,8 @@ SIGNATURES = {
     "meant_add_rowvec_bwd": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "meant_gelu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "meant_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "meant_geglu_fwd": (_i, [_p, _p, _i64, _i64, _i, _p]),
+    "meant_geglu_bwd": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
     "meant_add": (_i, [_p, _p, _p, _i64, _i, _p]),
     "meant_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
     "meant_transpose2d": (_i, [_p, _i, _p, _i, _i64, _i64, _p]),

@@ -206,6 +206,43 @@ __global__ __launch_bounds__(EW_THREADS) void patchify_raw_kernel(const TI* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// GEGLU (src/meant/timesformer_pytorch.py:60-63): h = [a | g] of width 2w per row -> y = a * gelu(g) of width w;
+// backward: dh = [dy * gelu(g) | dy * a * gelu'(g)].  One pass each, 16-byte accesses (w % 8 == 0).
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, int64_t rows, int w) {
+  const int cw = w >> 3;
+  const int64_t total = rows * cw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cw;
+    const int c = (int)(i - r * cw) * 8;
+    const Vec8<T> a = load8<T>(h + r * 2 * w + c), g = load8<T>(h + r * 2 * w + w + c);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.set(k, a.get(k) * gelu_erf(g.get(k)));
+    store8<T>(y + r * w + c, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dy, T* __restrict__ dh,
+                                                                int64_t rows, int w) {
+  const int cw = w >> 3;
+  const int64_t total = rows * cw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cw;
+    const int c = (int)(i - r * cw) * 8;
+    const Vec8<T> a = load8<T>(h + r * 2 * w + c), g = load8<T>(h + r * 2 * w + w + c), d = load8<T>(dy + r * w + c);
+    Vec8<T> da, dg;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      da.set(k, d.get(k) * gelu_erf(g.get(k)));
+      dg.set(k, d.get(k) * a.get(k) * gelu_erf_grad(g.get(k)));
+    }
+    store8<T>(dh + r * 2 * w + c, da);
+    store8<T>(dh + r * 2 * w + w + c, dg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8 mean over the sequence axis.  block = (g, 256-column slab): 32 chunks x 8 row groups.
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__ x, TO* __restrict__ out, int64_t ld_out,
@@ -432,6 +469,27 @@ extern "C" int meant_sigmoid_bwd(const void* dy, const void* y, void* dx, int64_
 }
 extern "C" int meant_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
   return launch_ew2(a, b, y, n, dtype, stream, AddOp(), "add");
+}
+
+extern "C" int meant_geglu_fwd(const void* h, void* y, int64_t rows, int64_t w, int dtype, void* stream) {
+  EW_REQ(h && y && rows >= 0 && w > 0 && w % 8 == 0 && w < (1LL << 30), "geglu_fwd: bad argument (w must be a multiple of 8)");
+  EW_REQ(meant_aligned16(h) && meant_aligned16(y), "geglu_fwd: 16-byte alignment");
+  if (rows == 0) return MEANT_OK;
+  const int64_t total = rows * (w >> 3);
+  const dim3 grid((unsigned)(ceil_div(total, EW_THREADS) < 65535 * 8 ? ceil_div(total, EW_THREADS) : 65535 * 8)), block(EW_THREADS);
+  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(geglu_fwd_kernel<T>, grid, block, 0, (hipStream_t)stream, (const T*)h, (T*)y, rows, (int)w));
+  MEANT_LAUNCH_CHECK("geglu_fwd");
+  return MEANT_OK;
+}
+extern "C" int meant_geglu_bwd(const void* h, const void* dy, void* dh, int64_t rows, int64_t w, int dtype, void* stream) {
+  EW_REQ(h && dy && dh && rows >= 0 && w > 0 && w % 8 == 0 && w < (1LL << 30), "geglu_bwd: bad argument (w must be a multiple of 8)");
+  EW_REQ(meant_aligned16(h) && meant_aligned16(dy) && meant_aligned16(dh), "geglu_bwd: 16-byte alignment");
+  if (rows == 0) return MEANT_OK;
+  const int64_t total = rows * (w >> 3);
+  const dim3 grid((unsigned)(ceil_div(total, EW_THREADS) < 65535 * 8 ? ceil_div(total, EW_THREADS) : 65535 * 8)), block(EW_THREADS);
+  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(geglu_bwd_kernel<T>, grid, block, 0, (hipStream_t)stream, (const T*)h, (const T*)dy, (T*)dh, rows, (int)w));
+  MEANT_LAUNCH_CHECK("geglu_bwd");
+  return MEANT_OK;
 }
 
 extern "C" int meant_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t n, void* stream) {

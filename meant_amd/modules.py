@@ -606,3 +606,133 @@ class meant_vision_pretrainer(nn.Module):
             y = y.view(b, hw, hw, co, r, r).permute(0, 3, 1, 4, 2, 5).reshape(b, co, hw * r, hw * r)
             return y
         return dec(x.permute(0, 2, 1).reshape(b, c, hw, hw))
+
+
+# ------------------------------------------------------------------------------------------
+# divided space-time attention as the fork's TimeSformer defines it
+# (src/meant/timesformer_pytorch.py:89-259, src/utils/rotary.py).  state_dict keys follow the reference:
+# to_patch_embedding.*, cls_token, frame_rot_emb.inv_freqs, image_rot_emb.scales, layers.i.{0,1}.{norm.*, fn.to_qkv.weight,
+# fn.to_out.0.*}, layers.i.2.{norm.*, fn.net.0.*, fn.net.3.*}, to_out.{0,1}.*.
+class _TSAttention(nn.Module):
+    """One half of the divided pair (timesformer_pytorch.py:89-148).  On the device: one projection GEMM for all
+    tokens; the cls query's attention over every token (1 x (1 + f n) per head: negligible) in fp32 torch ops; the patch
+    tokens gathered into their groups ('(b n) f' or '(b f) n') with the cls key / value replicated at position 0 of
+    every group, rotated (row 0 of the tables is the identity) and run through the flash attention core; the outputs of
+    position 0 are discarded, the rest scattered back to token order; output projection."""
+
+    def __init__(self, dim, dim_head=64, heads=8):
+        super().__init__()
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        inner = dim_head * heads
+        self.to_qkv = Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Sequential(Linear(inner, dim), nn.Identity())
+
+    def forward(self, x, mode, f, n, tables, index, residual=None):
+        b, L, _ = x.shape
+        h, dh = self.heads, self.dim_head
+        inner = h * dh
+        qkv = self.to_qkv(x)                                             # [b, 1 + f n, 3 inner]
+        # cls query against all (unrotated) keys / values
+        q0 = qkv[:, :1, :inner].float().view(b, 1, h, dh).transpose(1, 2) * self.scale
+        kk = qkv[:, :, inner:2 * inner].float().view(b, L, h, dh).transpose(1, 2)
+        vv = qkv[:, :, 2 * inner:].float().view(b, L, h, dh).transpose(1, 2)
+        cls_out = (torch.softmax(q0 @ kk.transpose(-1, -2), dim=-1) @ vv).transpose(1, 2).reshape(b, 1, inner).to(x.dtype)
+        # groups: index [G, S] of token positions (position 0 of every group = the cls token)
+        G, S = index.shape
+        grouped = ops.group_gather(qkv, index)                           # [b, G, S, 3 inner]
+        og = ops.attention_core(grouped.reshape(b * G * S, 3 * inner), b * G, S, h, self.scale, tables)
+        og = og.view(b, G, S, inner)[:, :, 1:]                           # drop the cls rows
+        if mode == "time":
+            og = og.transpose(1, 2)                                      # (n, f) -> (f, n)
+        out = torch.cat((cls_out, og.reshape(b, f * n, inner)), dim=1)
+        return self.to_out[0](out, residual=residual)                    # the block's `+ x` rides the GEMM epilogue
+
+
+class _TSPreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn, self.norm = fn, LayerNorm(dim)
+
+
+class _TSFeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(Linear(dim, dim * mult * 2), nn.Identity(), nn.Identity(), Linear(dim * mult, dim))
+
+    def forward(self, x, residual=None):
+        return self.net[3](ops.geglu(self.net[0](x)), residual=residual)
+
+
+class TimeSformer(nn.Module):
+    """src/meant/timesformer_pytorch.py:152-259 with rotary embeddings, no token shift, no frame mask (the variants the
+    fork's models use, src/meant/meant_vision.py:130-162).  `meant_forward(video)` returns all tokens [b, 1 + f n, dim],
+    `forward` the class logits of the cls token."""
+
+    def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64,
+                 attn_dropout=0., ff_dropout=0., rotary_emb=True, shift_tokens=False):
+        super().__init__()
+        if not rotary_emb or shift_tokens or attn_dropout or ff_dropout:
+            raise NotImplementedError("meant_amd.TimeSformer: only rotary_emb=True, shift_tokens=False, zero dropout are on the path")
+        assert image_size % patch_size == 0, "Image dimensions must be divisible by the patch size."
+        self.heads, self.patch_size, self.dim_head, self.num_frames = heads, patch_size, dim_head, num_frames
+        self.to_patch_embedding = Linear(channels * patch_size ** 2, dim)
+        self.cls_token = nn.Parameter(torch.randn(1, dim))
+        self.frame_rot_emb = nn.Module()
+        self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
+        self.image_rot_emb = nn.Module()
+        self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
+        self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
+                                                    _TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
+                                                    _TSPreNorm(dim, _TSFeedForward(dim))]) for _ in range(depth)])
+        self.to_out = nn.Sequential(LayerNorm(dim), Linear(dim, num_classes))
+        self._cache = {}
+
+    def _plan(self, f, hp, wp, device):
+        """rotary tables with an identity row for the cls position, and the gather indices of both groupings"""
+        key = (f, hp, wp, str(device))
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        n = hp * wp
+        with torch.no_grad():
+            inv = self.frame_rot_emb.inv_freqs.detach().float().cpu()
+            fr = torch.arange(f).float()[:, None] * inv[None, :]
+            fr = torch.cat((fr, fr), dim=-1)                                                 # [f, Dh] (src/utils/rotary.py:57-60)
+            sc = self.image_rot_emb.scales.detach().float().cpu()[None, :]
+            hs = torch.linspace(-1., 1., hp)[:, None] * sc * math.pi
+            ws = torch.linspace(-1., 1., wp)[:, None] * sc * math.pi
+            ang = torch.cat((hs[:, None, :].expand(hp, wp, -1), ws[None, :, :].expand(hp, wp, -1)), dim=-1).reshape(n, -1)
+            ang = ang.repeat_interleave(2, dim=-1)                                            # [n, Dh] (:46-48)
+
+            def tabs(a):
+                cos = torch.cat((torch.ones(1, a.shape[1]), a.cos())).contiguous().to(device)   # row 0: cls, not rotated
+                sin = torch.cat((torch.zeros(1, a.shape[1]), a.sin())).contiguous().to(device)
+                return (cos, sin, cos, sin)
+            tok = 1 + torch.arange(f * n).view(f, n)
+            zero = torch.zeros(1, dtype=torch.long)
+            idx_time = torch.stack([torch.cat((zero, tok[:, j])) for j in range(n)]).to(device)   # [n, 1 + f]
+            idx_space = torch.stack([torch.cat((zero, tok[i, :])) for i in range(f)]).to(device)  # [f, 1 + n]
+            plan = (tabs(fr), tabs(ang), idx_time, idx_space)
+        self._cache = {key: plan}
+        return plan
+
+    def meant_forward(self, video, mask=None):
+        if mask is not None:
+            raise NotImplementedError("meant_amd.TimeSformer: frame masks are not on the path")
+        b, f, c, hh, ww = video.shape
+        p = self.patch_size
+        assert hh % p == 0 and ww % p == 0, f"height {hh} and width {ww} of video must be divisible by the patch size {p}"
+        hp, wp = hh // p, ww // p
+        n = hp * wp
+        dt = resolve_compute_dtype(self, video)
+        tokens = self.to_patch_embedding(ops.patchify(video.reshape(b * f, c, hh, ww), p, dt)).view(b, f * n, -1)
+        x = torch.cat((self.cls_token.to(dt)[None].expand(b, -1, -1), tokens), dim=1)
+        t_time, t_space, idx_time, idx_space = self._plan(f, hp, wp, video.device)
+        for ta, sa, ff in self.layers:
+            x = ta.fn(ta.norm(x), "time", f, n, t_time, idx_time, residual=x)
+            x = sa.fn(sa.norm(x), "space", f, n, t_space, idx_space, residual=x)
+            x = ff.fn(ff.norm(x), residual=x)
+        return x
+
+    def forward(self, video, mask=None):
+        return self.to_out(self.meant_forward(video, mask=mask)[:, 0])

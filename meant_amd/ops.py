@@ -717,3 +717,110 @@ def softmax_cross_entropy(logits, target, ignore_index: int = -100):
     if Vp != V or not l2.is_contiguous():
         l2 = torch.nn.functional.pad(l2, (0, Vp - V))
     return _SoftmaxCE.apply(l2, target.reshape(-1), V, ignore_index)
+
+
+# ---------------------------------------------------------------------------------------------
+# attention core on an already projected, packed q|k|v buffer (the divided space-time attention of
+# src/meant/timesformer_pytorch.py regroups tokens between the projection and the core)
+class _AttentionCore(torch.autograd.Function):
+    """softmax(q k^T * scale [+ key padding]) v per group of S rows, on packed [G*S, 3*H*Dh] (q | k | v).  `tables` =
+    (qa, qb, ka, kb) float [S, R] rotate q and k first (meant_rotary_qk); the backward applies the adjoint inside the
+    attention backward kernel and returns the gradient w.r.t. the UNROTATED buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, tables, G, S, H, scale, causal, key_mask):
+        _need_gpu(qkv)
+        dt = _dt(qkv)
+        D3 = qkv.shape[-1]
+        D = D3 // 3
+        Dh = D // H
+        qa, qb, ka, kb = tables if tables is not None else (None, None, None, None)
+        R = qa.shape[1] if qa is not None else 0
+        q2 = qkv.reshape(G * S, D3)
+        if qa is not None:
+            q2 = q2.clone() if q2.data_ptr() == qkv.data_ptr() else q2
+            check(lib.meant_rotary_qk(_p(q2), G * S, S, H, Dh, R, _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()), "rotary_qk")
+        else:
+            q2 = _c(q2)
+        o = torch.empty((G * S, D), device=qkv.device, dtype=qkv.dtype)
+        lse = torch.empty((G, H, S, 2), device=qkv.device, dtype=torch.float32)
+        km = _c(key_mask.float()) if key_mask is not None else None
+        wsb = lib.meant_attn_ws(G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=qkv.device, dtype=torch.uint8)
+        check(lib.meant_attn_fwd(_p(q2), _p(o), _p(lse), _p(km), G, S, H, Dh, float(scale), int(causal), dt, _p(ws), wsb, _stream()), "attn_fwd")
+        ctx.save_for_backward(q2, o, lse, km)
+        ctx.tables, ctx.meta, ctx.in_shape = tables, (G, S, H, Dh, float(scale), int(causal)), qkv.shape
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q2, o, lse, km = ctx.saved_tensors
+        G, S, H, Dh, scale, causal = ctx.meta
+        do2 = _c(do)
+        dt = _dt(do2)
+        dqkv = torch.empty_like(q2)
+        wsb = lib.meant_attn_ws(G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=do2.device, dtype=torch.uint8)
+        qa, qb, ka, kb = ctx.tables if ctx.tables is not None else (None, None, None, None)
+        R = qa.shape[1] if qa is not None else 0
+        check(lib.meant_attn_bwd(_p(q2), _p(o), _p(do2), _p(lse), _p(km), _p(dqkv), G, S, H, Dh, scale, causal,
+                                 _p(qa), _p(qb), _p(ka), _p(kb), R, dt, _p(ws), wsb, _stream()), "attn_bwd")
+        return dqkv.view(ctx.in_shape), None, None, None, None, None, None, None
+
+
+def attention_core(qkv, G, S, H, scale, tables=None, causal=False, key_mask=None):
+    """qkv: [G*S, 3*H*Dh] (or any shape with that many elements per row) -> o [G*S, H*Dh]"""
+    return _AttentionCore.apply(qkv, tables, int(G), int(S), int(H), float(scale), bool(causal), key_mask)
+
+
+class _GEGLU(torch.autograd.Function):
+    """a * gelu(g) on h = [a | g] (src/meant/timesformer_pytorch.py:60-63), one pass forward and one backward"""
+
+    @staticmethod
+    def forward(ctx, h):
+        _need_gpu(h)
+        h2 = _c(h).view(-1, h.shape[-1])
+        rows, w2 = h2.shape
+        y = torch.empty((rows, w2 // 2), device=h.device, dtype=h.dtype)
+        check(lib.meant_geglu_fwd(_p(h2), _p(y), rows, w2 // 2, _dt(h2), _stream()), "geglu_fwd")
+        ctx.save_for_backward(h2)
+        ctx.shape = h.shape
+        return y.view(*h.shape[:-1], w2 // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h2,) = ctx.saved_tensors
+        rows, w2 = h2.shape
+        d2 = _c(dy).view(rows, w2 // 2)
+        dh = torch.empty_like(h2)
+        check(lib.meant_geglu_bwd(_p(h2), _p(d2), _p(dh), rows, w2 // 2, _dt(h2), _stream()), "geglu_bwd")
+        return dh.view(ctx.shape)
+
+
+def geglu(h):
+    return _GEGLU.apply(h)
+
+
+class _GroupGather(torch.autograd.Function):
+    """x[:, index] for an index [G, S] whose column 0 is the same row (the cls token) in every group and whose other
+    entries are a permutation of the remaining rows: the backward is a copy (no atomics) plus one sum for the cls row"""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.rows = x.shape[1]
+        G, S = index.shape
+        return x.index_select(1, index.reshape(-1)).view(x.shape[0], G, S, x.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        (index,) = ctx.saved_tensors
+        b, G, S, d = dout.shape
+        dx = dout.new_empty((b, ctx.rows, d))
+        dx.index_copy_(1, index[:, 1:].reshape(-1), dout[:, :, 1:].reshape(b, G * (S - 1), d))
+        dx[:, index[0, 0]] = dout[:, :, 0].sum(dim=1)
+        return dx, None
+
+
+def group_gather(x, index):
+    return _GroupGather.apply(x, index)

@@ -445,6 +445,123 @@ class meant_vqa(nn.Module):
 # deterministic weights / inputs shared by gen_golden.py, the tests and bench.py
 # (SURVEY.md section 8c "fixture recipe": numpy RandomState only, no torch RNG)
 # --------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------
+# a16 / 8f-4  divided space-time attention          reference: src/meant/timesformer_pytorch.py
+# --------------------------------------------------------------------------------------
+def _rot_pairs_full(t, sin, cos):
+    """src/utils/rotary.py:7-19: t * cos + rotate_every_two(t) * sin on the first sin.shape[-1] lanes (adjacent pairs
+    (x0, x1) -> (-x1, x0)), remaining lanes untouched"""
+    r = sin.shape[-1]
+    a, rest = t[..., :r], t[..., r:]
+    x0, x1 = a[..., 0::2], a[..., 1::2]
+    rot = torch.stack((-x1, x0), dim=-1).flatten(-2)
+    return torch.cat((a * cos + rot * sin, rest), dim=-1)
+
+
+class _TSAttention(nn.Module):
+    """src/meant/timesformer_pytorch.py:89-148.  One attention of the divided pair: the cls token attends to every
+    token (:124); the patch tokens are regrouped along time ('(b n) f d') or space ('(b f) n d'), rotated (:130-131,
+    cls excluded), and attend within their group to [cls, group] (:134-141)."""
+
+    def __init__(self, dim, dim_head=64, heads=8):
+        super().__init__()
+        self.heads, self.scale = heads, dim_head ** -0.5
+        inner = dim_head * heads
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Identity())      # Dropout(0.) at index 1 in the reference
+
+    def forward(self, x, mode, f, n, rot):
+        b, _, _ = x.shape
+        h = self.heads
+        q, k, v = self.to_qkv(x).chunk(3, dim=-1)
+        split = lambda t: t.reshape(b, -1, h, t.shape[-1] // h).permute(0, 2, 1, 3)       # b h tokens d
+        q, k, v = split(q) * self.scale, split(k), split(v)
+        cls_out = torch.softmax(q[:, :, :1] @ k.transpose(-1, -2), dim=-1) @ v               # b h 1 d
+        d = q.shape[-1]
+
+        def group(t):                                                                        # patch tokens -> groups
+            t = t[:, :, 1:].reshape(b, h, f, n, d)
+            return t.permute(0, 1, 3, 2, 4) if mode == "time" else t                         # b h n f d | b h f n d
+        qg, kg, vg = group(q), group(k), group(v)
+        sin, cos = rot
+        qg, kg = _rot_pairs_full(qg, sin, cos), _rot_pairs_full(kg, sin, cos)
+        G = qg.shape[2]
+        ck = k[:, :, :1].unsqueeze(2).expand(b, h, G, 1, d)
+        cv = v[:, :, :1].unsqueeze(2).expand(b, h, G, 1, d)
+        kg, vg = torch.cat((ck, kg), dim=3), torch.cat((cv, vg), dim=3)
+        og = torch.softmax(qg @ kg.transpose(-1, -2), dim=-1) @ vg                           # b h G L d
+        if mode == "time":
+            og = og.permute(0, 1, 3, 2, 4)                                                   # b h f n d
+        out = torch.cat((cls_out, og.reshape(b, h, f * n, d)), dim=2)
+        return self.to_out(out.permute(0, 2, 1, 3).reshape(b, 1 + f * n, h * d))
+
+
+class _TSPreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn, self.norm = fn, nn.LayerNorm(dim)
+
+
+class _TSFeedForward(nn.Module):
+    """:66-77: Linear(d, 8d) -> GEGLU (x * gelu(gates), :60-63) -> Dropout(0) -> Linear(4d, d)"""
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), nn.Identity(), nn.Identity(), nn.Linear(dim * mult, dim))
+
+    def forward(self, x):
+        a, g = self.net[0](x).chunk(2, dim=-1)
+        return self.net[3](a * F.gelu(g))
+
+
+class TimeSformer(nn.Module):
+    """src/meant/timesformer_pytorch.py:152-259 with rotary_emb=True, shift_tokens=False, no frame mask (what the
+    fork's callers use, src/meant/meant_vision.py:130-162).  Frame rotary: angle = frame * 10000^(-2j/Dh) laid out
+    cat(freqs, freqs) (src/utils/rotary.py:51-62); axial rotary: logspace(0, log2(max_freq/2), Dh/4, base 2) * pi *
+    linspace(-1, 1) along h then w, each angle repeated on a lane pair (:21-49); both rotate adjacent pairs."""
+
+    def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64):
+        super().__init__()
+        self.heads, self.patch_size, self.dim_head = heads, patch_size, dim_head
+        self.to_patch_embedding = nn.Linear(channels * patch_size ** 2, dim)
+        self.cls_token = nn.Parameter(torch.randn(1, dim))
+        self.frame_rot_emb = nn.Module()
+        self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
+        self.image_rot_emb = nn.Module()
+        self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
+        self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
+                                                    _TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
+                                                    _TSPreNorm(dim, _TSFeedForward(dim))]) for _ in range(depth)])
+        self.to_out = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
+
+    def rotary_tables(self, f, hp, wp):
+        fr = torch.arange(f).float()[:, None] * self.frame_rot_emb.inv_freqs[None, :]
+        fr = torch.cat((fr, fr), dim=-1)                                                      # [f, Dh]
+        sc = self.image_rot_emb.scales[None, :]
+        hs = torch.linspace(-1., 1., hp)[:, None] * sc * math.pi
+        ws = torch.linspace(-1., 1., wp)[:, None] * sc * math.pi
+        ang = torch.cat((hs[:, None, :].expand(hp, wp, -1), ws[None, :, :].expand(hp, wp, -1)), dim=-1).reshape(hp * wp, -1)
+        ang = ang.repeat_interleave(2, dim=-1)                                                # [n, Dh]
+        return (fr.sin(), fr.cos()), (ang.sin(), ang.cos())
+
+    def meant_forward(self, video):
+        b, f, c, hh, ww = video.shape
+        p = self.patch_size
+        hp, wp = hh // p, ww // p
+        n = hp * wp
+        tok = video.reshape(b, f, c, hp, p, wp, p).permute(0, 1, 3, 5, 4, 6, 2).reshape(b, f * n, p * p * c)   # (p1 p2 c)
+        x = torch.cat((self.cls_token[None].expand(b, -1, -1), self.to_patch_embedding(tok)), dim=1)
+        frame_rot, image_rot = self.rotary_tables(f, hp, wp)
+        for ta, sa, ff in self.layers:
+            x = ta.fn(ta.norm(x), "time", f, n, frame_rot) + x
+            x = sa.fn(sa.norm(x), "space", f, n, image_rot) + x
+            x = ff.fn(ff.norm(x)) + x
+        return x
+
+    def forward(self, video):
+        return self.to_out(self.meant_forward(video)[:, 0])
+
+
 class meant_language_pretrainer(nn.Module):
     """pretrain_mlm.py:74-88 -- the MLM pretrainer: a caller-supplied embedding module (the reference passes HF
     `RobertaForMaskedLM(...).roberta.embeddings`, :318), `num_encoders` languageEncoders (default num_heads = 8) and a

@@ -318,3 +318,39 @@ def test_mim_pretrainer_golden(dev, golden, dtype):
     for nm, refn in zip(g["grad_names"], g["grad_norms"]):
         got = params[str(nm)].grad.double().norm().item()
         assert abs(got - refn) <= tol_g * max(refn, floor), (str(nm), got, refn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_timesformer_golden(dev, golden, dtype):
+    """divided space-time attention (time then space, cls token, frame + axial rotary, GEGLU)
+    against the fork's TimeSformer (fixture from src/meant/timesformer_pytorch.py)"""
+    import meant_amd as M
+    from oracle import meant_oracle as O
+    g = golden("timesformer_tiny")
+    torch.manual_seed(0)
+    m = M.TimeSformer(dim=128, num_frames=3, num_classes=5, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64)
+    O.fill_weights_(m, 8642)
+    m = m.to(dev).eval()
+    m.compute_dtype = dtype
+    x = m.meant_forward(torch.from_numpy(g["video"]).to(dev))
+    logits = m.to_out(x[:, 0])
+    assert x.shape == (2, 13, 128) and logits.shape == (2, 5)
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    assert (x.float().cpu() - torch.from_numpy(g["tokens"])).abs().max().item() < tol * float(np.abs(g["tokens"]).max())
+    assert (logits.float().cpu() - torch.from_numpy(g["logits"])).abs().max().item() < tol * max(1.0, float(np.abs(g["logits"]).max()))
+    loss = torch.nn.functional.cross_entropy(logits.float(), torch.from_numpy(g["target"]).to(dev)) + 0.01 * x.float().pow(2).mean()
+    assert abs(loss.item() - float(g["loss"])) < (1e-4 if dtype == torch.float32 else 2e-2) * float(g["loss"])
+    loss.backward()
+    params = dict(m.named_parameters())
+    tol_g = 2e-3 if dtype == torch.float32 else 6e-2
+    floor = 1e-3 * float(np.max(g["grad_norms"]))
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        got = params[str(nm)].grad.double().norm().item()
+        assert abs(got - refn) <= tol_g * max(refn, floor), (str(nm), got, refn)
+    for k in g.files:
+        if k.startswith("grad__"):
+            p_ = params[k[6:]]
+            ref = torch.from_numpy(g[k])
+            got = (p_.grad if p_.grad.numel() <= 4096 else p_.grad[:4]).float().cpu()
+            assert (got - ref).abs().max().item() <= tol_g * max(ref.abs().max().item(), floor), k

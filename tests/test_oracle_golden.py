@@ -209,3 +209,23 @@ def test_mim_pretrainer_tiny(golden):
     for nm, refn in zip(g["grad_names"], g["grad_norms"]):
         got = params[str(nm)].grad.double().norm().item()
         assert abs(got - refn) <= 1e-4 * max(refn, 1e-6), (nm, got, refn)
+
+
+def test_timesformer_tiny(golden):
+    """the oracle's divided space-time attention (cls token, frame + axial rotary, GEGLU) against
+    the fork's TimeSformer (src/meant/timesformer_pytorch.py), tokens / logits / loss / gradients"""
+    g = golden("timesformer_tiny")
+    torch.manual_seed(0)
+    m = O.TimeSformer(dim=128, num_frames=3, num_classes=5, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64).eval()
+    O.fill_weights_(m, 8642)
+    x = m.meant_forward(torch.from_numpy(g["video"]))
+    logits = m.to_out(x[:, 0])
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["target"])) + 0.01 * x.pow(2).mean()
+    loss.backward()
+    assert (x.detach() - torch.from_numpy(g["tokens"])).abs().max().item() < 5e-6 * float(np.abs(g["tokens"]).max())
+    assert (logits.detach() - torch.from_numpy(g["logits"])).abs().max().item() < 1e-5 * max(1.0, float(np.abs(g["logits"]).max()))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    params = dict(m.named_parameters())
+    for nm, refn in zip(g["grad_names"], g["grad_norms"]):
+        got = params[str(nm)].grad.double().norm().item()
+        assert abs(got - refn) <= 1e-4 * max(refn, 1e-6), (nm, got, refn)
