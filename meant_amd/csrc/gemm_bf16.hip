@@ -875,6 +875,22 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
     MEANT_REQUIRE(ntm2 * ntn2 < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
     // MEANT_NT_STREAM=0 forces the one-tile-per-workgroup kernel (A/B measurements)
     static const bool stream_ok = !(getenv("MEANT_NT_STREAM") && atoi(getenv("MEANT_NT_STREAM")) == 0);
+    // Ragged M: the streaming kernel takes the first floor(M / 256) * 256 rows, the remaining < 256 rows go to the
+    // 128 x 128 kernel as a second launch (row-local epilogues only: the rotary epilogue indexes its tables by the
+    // absolute row, so it splits only where the boundary is a multiple of the sequence length).
+    const int64_t m_full = (a.M / B2) * B2;
+    if (stream_ok && m_full >= 1024 && m_full != a.M && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
+        (!a.rot_qa || m_full % a.rot_S == 0)) {
+      GemmBf16Args head = a, tail = a;
+      head.M = m_full;
+      tail.M = a.M - m_full;
+      tail.A = a.A + m_full * a.lda;
+      tail.C = a.C + m_full * a.ldc;
+      if (a.residual) tail.residual = a.residual + m_full * a.ldr;
+      if (a.preact) tail.preact = a.preact + m_full * a.ldc;
+      const int rc = gemm_bf16_nt_launch(head, stream);
+      return rc ? rc : gemm_bf16_nt_launch(tail, stream);
+    }
     if (stream_ok && a.M % B2 == 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
       const int ncu = meant_num_cus() & ~7;
       const int grid = (int)(ntm2 * ntn2 < ncu ? ((ntm2 * ntn2 + 7) / 8) * 8 : ncu);

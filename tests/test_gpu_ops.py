@@ -112,12 +112,12 @@ def test_layernorm(M, dev, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("M_,N,K", [(300, 768, 768), (64, 2304, 768), (1000, 128, 1024), (5, 2, 1536), (257, 3129, 256),
-                                     (128, 128, 128), (4097, 768, 768), (2048, 768, 256), (1536, 512, 128)])
+                                     (128, 128, 128), (4097, 768, 768), (2048, 768, 256), (1536, 512, 128), (1300, 256, 128)])
 @pytest.mark.parametrize("epi", ["none", "gelu", "residual", "sigmoid"])
 def test_linear(M, dev, dtype, M_, N, K, epi):
     from meant_amd import ops
     from meant_amd._lib import EPI_NONE, EPI_GELU, EPI_SIGMOID
-    if epi != "none" and (M_, N, K) not in [(300, 768, 768), (5, 2, 1536), (1000, 128, 1024), (2048, 768, 256)]:
+    if epi != "none" and (M_, N, K) not in [(300, 768, 768), (5, 2, 1536), (1000, 128, 1024), (2048, 768, 256), (1300, 256, 128)]:
         pytest.skip("epilogues are covered on four shapes")
     rs = np.random.RandomState(M_ + N)
     x = t(rs.standard_normal((M_, K)).astype("float32"))
