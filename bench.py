@@ -313,7 +313,8 @@ def main():
         h_labels = rs.randint(0, NCLS, (pool,)).astype(np.int64)
         if npdt == np.uint8:
             model.patchEmbed[0].set_normalization(127.5, 73.9)
-        loader = DeviceBatchLoader(h_graphs, h_tweets, None, h_masks, h_labels, batch_size=B, device=dev)
+        loader = DeviceBatchLoader(h_graphs, h_tweets, None, h_masks, h_labels, batch_size=B, device=dev,
+                                   pin_source_bytes=(1 << 20) if os.environ.get("MEANT_PIN_SOURCE") else 0)
 
         def host_steps(n):
             done = 0

@@ -11,7 +11,9 @@ What this does instead (one process per GPU, the GPU is the consumer):
   * pixels travel in their STORAGE type (float64 / float32 / uint8 -- nothing is converted or normalised on the
     host) and are turned into normalised bf16 patches by one kernel on the device (`meant_patchify_raw`, reached
     through the model's own patch embedding: `model.patchEmbed[0].set_normalization(mean, std)`);
-  * the gather into pinned memory runs on a small thread pool (torch releases the GIL inside index_select) and one
+  * arrays that live in RAM can be page-locked in place (`pin_source_bytes`): their rows then travel by DMA straight
+    out of the data set, one copy per sample, and the host touches no pixel at all;
+  * otherwise the gather into pinned memory runs on a small thread pool (torch releases the GIL inside index_select) and one
     batch AHEAD of the consumer on a producer thread, so it overlaps both the GPU step and the Python that launches it;
   * the global mean / std are one streaming pass over the array (`global_mean_std`), not two in-place passes that
     rewrite 19.3 MB per sample.
@@ -65,7 +67,7 @@ class DeviceBatchLoader:
     `arrays` are host numpy arrays (or memmaps) with a common leading dimension; `None` entries stay `None`."""
 
     def __init__(self, *arrays: Optional[np.ndarray], batch_size: int, device="cuda", shuffle: bool = False, seed: int = 0,
-                 rank: int = 0, world: int = 1, drop_last: bool = True):
+                 rank: int = 0, world: int = 1, drop_last: bool = True, pin_source_bytes: int = 0):
         assert any(a is not None for a in arrays), "no data"
         self.arrays = arrays
         self.n = next(a.shape[0] for a in arrays if a is not None)
@@ -78,8 +80,41 @@ class DeviceBatchLoader:
         assert drop_last, "partial batches are dropped (the kernels are tuned for the fixed batch shape)"
         self._stage = None
         self._stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        # Arrays that live in RAM (not memmaps) and are at least `pin_source_bytes` big can be page-locked IN PLACE
+        # (hipHostRegister): their rows then go to the device by DMA straight from the data set, one copy per sample,
+        # and the host never touches the pixels at all.  0 disables (default): registering is a one-time cost
+        # proportional to the array and needs the memory to stay resident.
+        self._registered = [False] * len(arrays)
+        if self.on_gpu and pin_source_bytes > 0:
+            rt = torch.cuda.cudart()
+            for i, a in enumerate(arrays):
+                if a is None or isinstance(a, np.memmap) or not a.flags["C_CONTIGUOUS"] or a.nbytes < pin_source_bytes:
+                    continue
+                try:
+                    rc = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+                    self._registered[i] = (int(rc) == 0)
+                except Exception:
+                    self._registered[i] = False
         self._workers = max(1, min(int(os.environ.get("MEANT_LOADER_THREADS", "8")), (os.cpu_count() or 2) // 2))
         self._pool = ThreadPoolExecutor(max_workers=self._workers)
+
+    def close(self):
+        """undo the in-place page-locking of the source arrays (also done on garbage collection)"""
+        if any(self._registered):
+            rt = torch.cuda.cudart()
+            for i, a in enumerate(self.arrays):
+                if self._registered[i]:
+                    try:
+                        rt.cudaHostUnregister(a.ctypes.data)
+                    except Exception:
+                        pass
+                    self._registered[i] = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __len__(self) -> int:
         return self.n // (self.batch_size * self.world)
@@ -101,24 +136,32 @@ class DeviceBatchLoader:
 
     def _fill_and_send(self, k: int, idx: np.ndarray):
         # multi-threaded gather straight into the pinned buffers (no intermediate copy, no conversion): each worker
-        # takes a contiguous slice of the batch
+        # takes a contiguous slice of the batch.  Page-locked source arrays skip this: see below.
         nw = self._workers
         bounds = [(i * len(idx)) // nw for i in range(nw + 1)]
+        staged = [a is not None and not self._registered[i] for i, a in enumerate(self.arrays)]
 
         def part(w):
             lo, hi = bounds[w], bounds[w + 1]
             if hi > lo:
                 sel = torch.from_numpy(np.ascontiguousarray(idx[lo:hi]))
-                for a, host in zip(self.arrays, self._stage[k]):
-                    if a is not None:
+                for a, host, st in zip(self.arrays, self._stage[k], staged):
+                    if st:
                         torch.index_select(torch.from_numpy(a) if not isinstance(a, torch.Tensor) else a, 0, sel, out=host[lo:hi])
-        list(self._pool.map(part, range(nw)))
+        if any(staged):
+            list(self._pool.map(part, range(nw)))
         if not self.on_gpu:
             self._dev[k] = [None if h is None else h.clone() for h in self._stage[k]]
             return
         with torch.cuda.stream(self._stream):
-            for host, dev in zip(self._stage[k], self._dev[k]):
-                if host is not None:
+            for i, (a, host, dev) in enumerate(zip(self.arrays, self._stage[k], self._dev[k])):
+                if host is None:
+                    continue
+                if self._registered[i]:                       # DMA row by row out of the page-locked data set
+                    src = torch.from_numpy(a)
+                    for j, r in enumerate(idx):
+                        dev[j].copy_(src[int(r)], non_blocking=True)
+                else:
                     dev.copy_(host, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._stream)

@@ -218,12 +218,17 @@ def test_model_on_device_batch_loader_float64(dev):
     model = M.meant(128, 128, 4, 32, 32, 16, L, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=1, channels=4).to(dev).eval()
     mean, std = global_mean_std(graphs)
     model.patchEmbed[0].set_normalization(mean, std)
-    loader = DeviceBatchLoader(graphs, tweets, None, masks, labels, batch_size=2, device=dev)
-    outs = []
-    for g, tw, _, am, y in loader:
-        assert g.dtype == torch.float64 and g.is_cuda
-        outs.append(model(tw.long(), g, am).float().cpu())
-    got = torch.cat(outs)
+    got = None
+    for pin in (0, 1):                                   # staged through pinned buffers / DMA out of the page-locked arrays
+        loader = DeviceBatchLoader(graphs, tweets, None, masks, labels, batch_size=2, device=dev, pin_source_bytes=pin)
+        outs = []
+        for g, tw, _, am, y in loader:
+            assert g.dtype == torch.float64 and g.is_cuda
+            outs.append(model(tw.long(), g, am).float().cpu())
+        loader.close()
+        if got is not None:
+            assert torch.equal(got, torch.cat(outs))
+        got = torch.cat(outs)
     model.patchEmbed[0].set_normalization(0.0, 1.0)
     gn = torch.from_numpy(((graphs - mean) / std).astype("float32")).to(dev)
     ref = model(torch.from_numpy(tweets).to(dev), gn, torch.from_numpy(masks).to(dev)).float().cpu()
