@@ -347,6 +347,17 @@ class _PatchEmbed(nn.Sequential):
         return self[1](self[0](images))
 
 
+def _run_encoder(enc, x, *args, checkpoint: bool = False):
+    """one encoder layer, optionally under activation recomputation: with `model.activation_checkpointing = True` only
+    the layer input is kept and the layer is re-run in backward (torch.utils.checkpoint restores the CPU RNG state, from
+    which the dropout seeds are drawn, so the recomputed masks are the forward's).  At the reference's CLI default of
+    12 encoder layers, 128 samples per GPU would otherwise save ~330 GB of activations."""
+    if checkpoint and torch.is_grad_enabled() and x.requires_grad:
+        from torch.utils.checkpoint import checkpoint as _ckpt
+        return _ckpt(enc, x, *args, use_reentrant=False, preserve_rng_state=True)
+    return enc(x, *args)
+
+
 def _embed(mods, ids, dtype):
     """meant/meant.py:210-211.  A plain nn.Embedding is served by the HIP gather kernel; any other
     user module (e.g. HF RobertaEmbeddings) is called as is and its output cast."""
@@ -399,23 +410,24 @@ class meant(nn.Module):
         # stack runs on a second HIP stream so that kernels with different bottlenecks (HBM-bound norms, load-path-bound
         # GEMMs, issue-bound attention) of the two stacks can share the chip.  Autograd replays each backward op on the
         # stream of its forward op, so the backward passes overlap the same way.
-        side = _side_stream(images.device) if (TWO_STREAMS and images.is_cuda) else None
+        ck = bool(getattr(self, "activation_checkpointing", False))
+        side = _side_stream(images.device) if (TWO_STREAMS and images.is_cuda and not ck) else None
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
                 for enc in self.visionEncoders:
-                    img = enc(img)
+                    img = _run_encoder(enc, img, checkpoint=ck)
         for enc in self.languageEncoders:
-            words = enc(words, attention_mask)
+            words = _run_encoder(enc, words, attention_mask, checkpoint=ck)
         if side is not None:
             main.wait_stream(side)
             img.record_stream(main)
         else:
             img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
             for enc in self.visionEncoders:
-                img = enc(img)
+                img = _run_encoder(enc, img, checkpoint=ck)
         fused = ops.meanpool_cat(words, img).view(B, self.lag, self.dim)
         for enc in self.temporal_encoding:
             fused = enc(fused)

@@ -359,3 +359,29 @@ def test_timesformer_golden(dev, golden, dtype):
             ref = torch.from_numpy(g[k])
             got = (p_.grad if p_.grad.numel() <= 4096 else p_.grad[:4]).float().cpu()
             assert (got - ref).abs().max().item() <= tol_g * max(ref.abs().max().item(), floor), k
+
+
+@pytest.mark.gpu
+def test_activation_checkpointing_same_gradients(dev):
+    """model.activation_checkpointing = True (the E = 12 memory switch): identical outputs and gradients, also in train
+    mode where the recomputation has to redraw the forward's dropout masks"""
+    import meant_amd as M
+    torch.manual_seed(0)
+    m = M.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=2, channels=4).to(dev).train()
+    m.compute_dtype = torch.bfloat16
+    rs = np.random.RandomState(4)
+    ids = torch.from_numpy(rs.randint(0, 100, (2, 3, 16))).to(dev)
+    img = torch.from_numpy(rs.standard_normal((2, 3, 4, 32, 32)).astype("float32")).to(dev)
+    mask = torch.ones(2, 3, 16, device=dev)
+    res = []
+    for ck in (False, True):
+        m.activation_checkpointing = ck
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(123)                               # same dropout seeds in both runs
+        out = m(ids, img, mask)
+        out.sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k, g0 in res[0][1].items():
+        g1 = res[1][1][k]
+        assert (g0 - g1).abs().max().item() <= 1e-5 * max(1.0, g0.abs().max().item()), k
