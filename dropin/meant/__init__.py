@@ -13,3 +13,4 @@ from .meant_vqa import meant_vqa  # noqa: F401
 from .xPosAttention import xPosAttention  # noqa: F401
 from .temporal import temporal  # noqa: F401
 from meant_amd.modules import xPosAttention_flash, flash_attention, RMSNorm  # noqa: F401
+from .hf_wrapper import meant_language_pretrainer, meant_vision_pretrainer  # noqa: F401

@@ -563,7 +563,7 @@ class meant_language_pretrainer(nn.Module):
         y = ops.linear(x, h.dense.weight, h.dense.bias, None, EPI_GELU)
         return ops.layernorm(y, h.layer_norm.weight, h.layer_norm.bias, h.layer_norm.eps)
 
-    def forward(self, words, attention_mask):
+    def forward(self, words, attention_mask=None):       # (meant/hf_wrapper.py:120 calls it without a mask)
         x = self._encode(words, attention_mask)
         h = self.mlm_head
         if _is_roberta_lm_head(h):
