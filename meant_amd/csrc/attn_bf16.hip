@@ -461,6 +461,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   const float* b2g = a.bias2 + (int64_t)g * ntile * KV_TILE;     // this group's bias tiles
   const int* flg = a.flags + (int64_t)g * ntile;
 
+  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue).  The first
+  // tile is requested before anything else: its round trip is the longest link of the workgroup's start-up chain.
+  const StageOff soff = make_stage_off(ld, S, wave, lane);
+  auto stage = [&](int t, int buf) {
+    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
+    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
+    if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
+  };
+  stage(0, 0);
+
   // Q fragments (B operand): lane (query = lane&31, half) holds Q[q][16ks + 8*half .. +7]
   bf16x8 qf[4];
   {
@@ -479,12 +489,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   // behind the DMA just issued for the next tile in the in-order vmcnt queue: waiting for the flag would drain the
   // DMA and serialise every tile's load with its math.)
   uint64_t special_mask = 0, skip_mask = 0;
-  const bool masks_ok = ntile <= 64;
-  if (masks_ok) {
-    const int f = lane < ntile ? flg[lane] : 0;
-    special_mask = __ballot(f & 1);
-    skip_mask = __ballot(f & 2);
-  }
+  const bool masks_ok = a.masks != nullptr;
+  if (masks_ok) sload_masks(a.masks + 2 * (int64_t)g, special_mask, skip_mask);   // one scalar load, not a vector load + ballots
   auto tile_flag = [&](int t) -> int {
     return masks_ok ? (int)((special_mask >> t) & 1) | ((int)((skip_mask >> t) & 1) << 1) : flg[t];
   };
@@ -498,16 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
   const float c1 = a.scale * LOG2E;
 
-  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
-  const StageOff soff = make_stage_off(ld, S, wave, lane);
-  auto stage = [&](int t, int buf) {
-    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
-    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
-    if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
-  };
   const TrOff troff = make_troff(lane);
-
-  stage(0, 0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -627,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 // backward, pass 1: dQ (and delta).  Same geometry as the forward.
 struct BwdArgs {
   const bf16* qkv; const bf16* o; const bf16* dout; const float* lse; const float* bias2; const int* flags; bf16* dqkv; float* delta;
+  const uint64_t* masks;                             // packed tile masks per group (null when S > 4096)
   int S, H; float scale; int causal;
   RotTables rot;                                     // adjoint rotary on dq / dk when rot.qa != null
 };
@@ -649,6 +647,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   const int* flg = a.flags + (int64_t)g * ntile;
   const int myq = q0 + (lane & 31);
   const int qrow = myq < S ? myq : S - 1;
+
+  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue).  The first
+  // tile is requested before anything else: its round trip is the longest link of the workgroup's start-up chain.
+  const StageOff soff = make_stage_off(ld, S, wave, lane);
+  auto stage = [&](int t, int buf) {
+    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
+    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
+    if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
+  };
+  stage(0, 0);
 
   bf16x8 qf[4], dof[4];
   float delta = 0.f;
@@ -683,12 +691,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   // behind the DMA just issued for the next tile in the in-order vmcnt queue: waiting for the flag would drain the
   // DMA and serialise every tile's load with its math.)
   uint64_t special_mask = 0, skip_mask = 0;
-  const bool masks_ok = ntile <= 64;
-  if (masks_ok) {
-    const int f = lane < ntile ? flg[lane] : 0;
-    special_mask = __ballot(f & 1);
-    skip_mask = __ballot(f & 2);
-  }
+  const bool masks_ok = a.masks != nullptr;
+  if (masks_ok) sload_masks(a.masks + 2 * (int64_t)g, special_mask, skip_mask);   // one scalar load, not a vector load + ballots
   auto tile_flag = [&](int t) -> int {
     return masks_ok ? (int)((special_mask >> t) & 1) | ((int)((skip_mask >> t) & 1) << 1) : flg[t];
   };
@@ -700,16 +704,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[b][e] = 0.f;
 
-  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
-  const StageOff soff = make_stage_off(ld, S, wave, lane);
-  auto stage = [&](int t, int buf) {
-    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
-    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
-    if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
-  };
   const TrOff troff = make_troff(lane);
-
-  stage(0, 0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -821,9 +816,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
   // keys of an all-padding tile get exactly zero dK / dV (flags bit 1): their waves sit the loop out, and a block
   // made of such tiles only writes its zeros
   const int* flg = a.flags + (int64_t)g * ntile;
-  const bool wave_dead = key0 < S && (flg[key0 / KV_TILE] & 2);
   const int kt_lo = kb0 / KV_TILE, kt_hi = (kb0 + 64 < S) ? kt_lo + 1 : kt_lo;
-  const bool block_dead = (flg[kt_lo] & 2) && (flg[kt_hi] & 2);
+  bool wave_dead, block_dead;
+  if (a.masks) {                                       // scalar load: the first DMA below depends on it
+    uint64_t sp, sk;
+    sload_masks(a.masks + 2 * (int64_t)g, sp, sk);
+    wave_dead = key0 < S && ((sk >> (key0 / KV_TILE)) & 1);
+    block_dead = ((sk >> kt_lo) & 1) && ((sk >> kt_hi) & 1);
+  } else {
+    wave_dead = key0 < S && (flg[key0 / KV_TILE] & 2);
+    block_dead = (flg[kt_lo] & 2) && (flg[kt_hi] & 2);
+  }
   const int nt = (S + 63) / 64;
   const int t0 = block_dead ? nt : (a.causal ? kb0 / 64 : 0);   // first query tile that can see this block's keys
 
@@ -1039,7 +1042,13 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
   hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal);
   MEANT_LAUNCH_CHECK("attn_prep_mask");
-  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, (int)S, H, scale, causal, rot};
+  uint64_t* masks = nullptr;
+  if (nt <= 64) {
+    masks = (uint64_t*)((char*)flags + ws_flag_bytes(G, S));
+    hipLaunchKernelGGL(attn_pack_flags_kernel, dim3((unsigned)G), dim3(64), 0, stream, flags, masks, nt);
+    MEANT_LAUNCH_CHECK("attn_pack_flags");
+  }
+  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, (int)S, H, scale, causal, rot};
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
