@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeant_hip.so")
+# MEANT_LIB_PATH: load another build of the same ABI (A/B measurements of one kernel against an older build)
+LIB_PATH = os.environ.get("MEANT_LIB_PATH") or os.path.join(_HERE, "libmeant_hip.so")
 
 F32, BF16 = 0, 1
 RAW_F32, RAW_BF16, RAW_F64, RAW_U8 = 0, 1, 2, 3      # meant_raw_dtype (input pipeline)

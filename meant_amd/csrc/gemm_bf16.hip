@@ -25,6 +25,7 @@
 // Roofline: MFMA-bound (dense bf16 peak 2.5 PFLOP/s); algorithmic FLOPs 2*M*N*K per launch.
 #include "internal.h"
 #include <type_traits>
+#include <atomic>
 
 namespace {
 
@@ -375,8 +376,28 @@ constexpr int RING = 5;
 //     prologue/epilogue).
 // Requirements (the launcher falls back to the kernels above otherwise): M % 256 == 0, N % 256 == 0, K % 64 == 0,
 // K >= 128, ldc % 8 == 0.
+// Tile hand-out of the streaming kernel.  A fixed walk (tile += grid) is fragile: when another kernel -- the other HIP stream's,
+// or a collective's -- holds a few CUs at launch, the workgroups that start late still own a full share of the tiles and the
+// launch takes ~1.5x as long (measured with 8 of 256 CUs pinned: 1.07 -> 1.66 ms).  So only the FIRST tile of a workgroup is
+// fixed; every further tile is drawn from a counter.  There is one counter per XCD so that the tiles an XCD works on stay
+// neighbours (shared A panels / weights in its L2); an XCD that runs dry steals from the next one.  Tile k of XCD x is
+// id(x, k) = (k / CH) * G + x * CH + k % CH with CH = G / 8 workgroups per XCD -- the same order as the fixed walk.
+// The draw costs no stall: lane 0 of wave 4 (a wave that issues no DMA) sends the atomic at the top of K-step 3 and picks the
+// answer up behind the wait that ends the step anyway; it publishes the tile id to a per-workgroup mailbox in global memory
+// (LDS is full) with a fire-and-forget store, acknowledged by the end of step 4; every wave requests the mailbox at the top of
+// step 5 and has it at the end of that step.  (Blocking versions of the same protocol cost 5-7 %: memory latency under this
+// kernel's own load is ~4 us, two K-steps.)  The last workgroup to leave zeroes the counters for the next launch.
+struct alignas(64) TileSched {
+  unsigned next[8];
+  unsigned done;
+  unsigned pad[7];
+  unsigned mailbox[512];
+};
+constexpr int N_SCHED_SLOTS = 256;
+__device__ TileSched g_tile_sched[N_SCHED_SLOTS];
+
 template <int DBG, bool ROT>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a, int ntm, int ntn) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a, int ntm, int ntn, TileSched* __restrict__ sched, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -384,8 +405,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   const int ntiles = ntm * ntn, G = gridDim.x;
   // workgroup b runs on XCD b % 8 (round-robin dispatch): in every round each XCD takes G/8 consecutive tile ids,
   // i.e. a few rows of tiles that share their A panels and all of W through that XCD's L2
-  int tile = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  if (tile >= ntiles) return;
+  const int CH = G >> 3, xcd = blockIdx.x & 7;
+  int tile = xcd * CH + (blockIdx.x >> 3);
+  const bool dynamic = sched != nullptr && nk >= 8;  // the draw travels during K-steps 3..5 and is needed at step nk - 2
+  auto leave = [&]() {                                 // last workgroup out resets the counters
+    if (sched && threadIdx.x == 0) {
+      if (atomicAdd(&sched->done, 1u) == (unsigned)G - 1u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sched->next[i] = 0;
+        sched->done = 0;
+      }
+    }
+  };
+  if (tile >= ntiles) { leave(); return; }
+  auto tile_of = [&](int x, unsigned k) { return (int)((k / (unsigned)CH) * (unsigned)G + (unsigned)(x * CH) + k % (unsigned)CH); };
 
   // waves 0-3 issue all DMA; wave w owns pieces 4w..4w+3 and 4(w+4)..4(w+4)+3 (1 KiB = 8 rows of 128 B) of every tile.
   // Piece p of a wave starts 8 * pp rows below its first one (pp = p, or p + 12 for the second group), which is a
@@ -415,9 +448,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   const bf16 *pA, *pB, *pAn = nullptr, *pBn = nullptr;      // operand origins of this tile and of the next one
   int64_t m0, n0, m0n = 0, n0n = 0;
   origin(tile, pA, pB, m0, n0);
-  int next = tile + G;
-  bool has_next = next < ntiles;
+  int next = dynamic ? -1 : tile + G;                  // dynamic: unknown until the draw of this tile has come back
+  bool has_next = !dynamic && next < ntiles;
   if (has_next) origin(next, pAn, pBn, m0n, n0n);
+  unsigned* mailbox = sched ? &sched->mailbox[blockIdx.x] : nullptr;
 
   if (issuer) {
     stage(pA, oA, a.lda, 0);
@@ -441,6 +475,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       const int sB = sA + 1 == RING ? 0 : sA + 1;
       const int s3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, s4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
       const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+      // tile draw, part 1 (see TileSched): requests only, nothing is waited for here -- they are older than this step's DMA,
+      // so the wait at the end of the step covers them.  The registers the answers land in are defined and consumed inside
+      // one iteration; hipcc does not know they are in flight, and tools/isa_inflight.py (run by tests/test_isa_guards.py)
+      // checks in the ISA that nothing touches them in between.
+      unsigned mail = 0, ticket = 0;
+      const bool reading = dynamic && kt == 5;
+      if (reading) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(mail) : "v"(mailbox) : "memory");
+      const bool drawer = dynamic && kt == 3 && wave == 4 && lane == 0;
+      if (drawer) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(&sched->next[xcd]), "v"(1u) : "memory");
       const bool more2 = in2 || has_next;
       if (issuer && !(DBG & 1)) {
         if (in1) stage(pB + (int64_t)(kt + 1) * BK, oB, a.ldb, s3);
@@ -475,8 +518,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       // the next step needs its A tile (issued a step ago) and its B tile (issued above); the A tile after that may
       // stay in flight.  The output stores of the previous tile are older than all of these and retire first.
       asm volatile("" ::: "memory");
-      if (more2 && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      // Waves 4-7 issue no DMA: all they can have in flight are old output stores and the requests above.  In the three
+      // steps of the draw they wait for everything (the stores are long gone by then).
+      const bool sched_step = dynamic && !issuer && kt >= 3 && kt <= 5;
+      if (more2 && !sched_step && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(mail), "+v"(ticket) : : "memory");
+      // tile draw, part 2: the answers are here
+      if (drawer) {                                    // K-step 3: resolve and publish (acknowledged by the end of step 4)
+        int id = tile_of(xcd, (unsigned)CH + ticket);
+        if (id >= ntiles) {                            // this XCD is dry: look at the others' counters, take from one with work left
+          unsigned seen[8];
+#pragma unroll
+          for (int x = 0; x < 8; ++x) seen[x] = __hip_atomic_load(&sched->next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int att = 1; id >= ntiles && att < 8; ++att) {
+            const int x2 = (xcd + att) & 7;
+            if (tile_of(x2, (unsigned)CH + seen[x2]) >= ntiles) continue;
+            id = tile_of(x2, (unsigned)CH + atomicAdd(&sched->next[x2], 1u));
+          }
+        }
+        const unsigned pub = id < ntiles ? (unsigned)id : 0xffffffffu;
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(mailbox), "v"(pub) : "memory");
+      }
+      if (reading) {                                   // K-step 5: every wave has read what was published
+        const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)mail);
+        next = mode == 2 ? (tile + G < ntiles ? tile + G : -1) : (int)got;
+        has_next = next >= 0;
+        if (has_next) origin(next, pAn, pBn, m0n, n0n);
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       sA = sA + 2 >= RING ? sA + 2 - RING : sA + 2;
@@ -591,10 +660,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     tile = next; pA = pAn; pB = pBn; m0 = m0n; n0 = n0n;
-    next += G;
-    has_next = next < ntiles;
-    if (has_next) origin(next, pAn, pBn, m0n, n0n);
+    if (dynamic) { next = -1; has_next = false; }
+    else {
+      next += G;
+      has_next = next < ntiles;
+      if (has_next) origin(next, pAn, pBn, m0n, n0n);
+    }
   }
+  leave();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -894,8 +967,16 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
     if (stream_ok && a.M % B2 == 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
       const int ncu = meant_num_cus() & ~7;
       const int grid = (int)(ntm2 * ntn2 < ncu ? ((ntm2 * ntn2 + 7) / 8) * 8 : ncu);
-      if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
-      else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
+      // one scheduler slot per launch, handed out round-robin (a slot is free again once its launch has finished; 256
+      // launches later is far beyond anything the step keeps in flight).  MEANT_NT_DYNAMIC=0 falls back to the fixed walk.
+      static TileSched* sched_base = nullptr;
+      static std::atomic<unsigned> sched_next{0};
+      static const int dynmode = getenv("MEANT_NT_DYNAMIC") ? atoi(getenv("MEANT_NT_DYNAMIC")) : 1;
+      const bool dyn = dynmode != 0;
+      if (!sched_base) (void)hipGetSymbolAddress((void**)&sched_base, HIP_SYMBOL(g_tile_sched));
+      TileSched* sched = (dyn && sched_base && grid <= 512) ? sched_base + (sched_next.fetch_add(1) % N_SCHED_SLOTS) : nullptr;
+      if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+      else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
     } else {
       hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
     }

@@ -1,0 +1,43 @@
+"""Build-time guard (no GPU): registers that inline asm leaves "in flight" in the streaming NT GEMM must not be touched by
+compiler-generated code before the wait that covers them (tools/isa_inflight.py explains why)."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("isa_inflight", os.path.join(ROOT, "tools", "isa_inflight.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_checker_flags_a_touched_register():
+    tool = _tool()
+    good = """_Z23gemm_bf16_nt256s_kernelv:
+	global_load_dword v9, v[2:3], off sc1
+	v_add_u32_e32 v4, v5, v6
+	s_waitcnt vmcnt(8)
+	v_readfirstlane_b32 s4, v9
+	s_endpgm
+"""
+    bad = good.replace("v_add_u32_e32 v4, v5, v6", "v_mov_b32_e32 v12, v9")
+    ranged = good.replace("v_add_u32_e32 v4, v5, v6", "ds_write_b128 v1, v[8:11]")
+    assert [r[4] for r in tool.check(good)] == [None]
+    assert tool.check(bad)[0][4] is not None
+    assert tool.check(ranged)[0][4] is not None
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_tile_draw_registers_stay_untouched_in_flight():
+    tool = _tool()
+    res = tool.check(tool.compile_to_isa())
+    # two kernel instantiations (plain / rotary epilogue), each with the mailbox read and the counter draw
+    assert len(res) == 4, res
+    for kernel, req, reg, n, bad in res:
+        assert bad is None, f"{kernel}: `{req}`: v{reg} touched while in flight by `{bad}`"
+        assert n > 100, f"{kernel}: `{req}` is no longer issued ahead of the K-step body ({n} instructions)"

@@ -11,10 +11,10 @@ template <int DBG> static void run(const char* name, GemmBf16Args a, int reps) {
   const int ntm = (int)(a.M / 256), ntn = (int)(a.N / 256);
   (void)hipFuncSetAttribute((const void*)KERNEL<DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(KERNEL<DBG, false>, dim3(PERSISTENT ? 256 : ntm * ntn), dim3(THREADS), LDSB, 0, a, ntm, ntn);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(KERNEL<DBG, false>, dim3(PERSISTENT ? 256 : ntm * ntn), dim3(THREADS), LDSB, 0, a, ntm, ntn, (TileSched*)nullptr);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(KERNEL<DBG, false>, dim3(PERSISTENT ? 256 : ntm * ntn), dim3(THREADS), LDSB, 0, a, ntm, ntn);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(KERNEL<DBG, false>, dim3(PERSISTENT ? 256 : ntm * ntn), dim3(THREADS), LDSB, 0, a, ntm, ntn, (TileSched*)nullptr);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   const double ksteps = (double)ntm * ntn / 256.0 * (a.K / 64);
