@@ -204,9 +204,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    # MEANT_REDUCE_ALWAYS=1: a one-rank RCCL group whose (trivial) collectives are really issued -- rehearsal on a one-GPU box
+    if args.gpus > 1 or world > 1 or os.environ.get("MEANT_REDUCE_ALWAYS") == "1":
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # rehearsal knobs for a one-GPU box: MEANT_DIST_BACKEND=gloo and MEANT_ALL_RANKS_ON_GPU0=1 run every rank on
         # cuda:0 over gloo to exercise the N>1 code path; the real multi-GPU run uses RCCL ("nccl"), one GPU per rank
         backend = os.environ.get("MEANT_DIST_BACKEND", "nccl")
@@ -359,7 +363,7 @@ def main():
                "config": {"workload": "full MEANT (tweet+image) fwd+CE+bwd, lag=12, d=768, 12 heads, seq=512, 224x224 p=16, "
                                       f"E={E}, vocab 64001 (BASELINE.json configs[2]/[3])",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "train_mode_dropout": not args.eval_mode, "activation_checkpointing": bool(args.checkpoint), "grad_allreduce": world > 1,
+                          "train_mode_dropout": not args.eval_mode, "activation_checkpointing": bool(args.checkpoint), "grad_allreduce": reducer.active,
                           "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1),
                           "gflop_per_sample_executed": round(flops_per_sample_executed(E) / 1e9, 1)},
                "roofline": roofline}
@@ -376,7 +380,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(E)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

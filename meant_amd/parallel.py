@@ -17,6 +17,7 @@ first layer, is reduced last.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -44,6 +45,11 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        # a one-rank group normally skips the collective; MEANT_REDUCE_ALWAYS=1 issues it anyway (used on a one-GPU box to
+        # run the real RCCL call sequence: hooks, stream ordering, async handles)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MEANT_REDUCE_ALWAYS") == "1")
+        # RCCL can average inside the collective (ncclAvg); gloo cannot, there the 1/world scaling is a separate pass
+        self.fused_avg = average and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         plist: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in plist:
@@ -78,6 +84,7 @@ class GradReducer:
             cur_n += _padded(p.numel())
         flush()
         self._owner = {}
+        self._launch_streams = {}
         for b in self.buckets:
             for p in b.params:
                 self._owner[id(p)] = b
@@ -106,24 +113,37 @@ class GradReducer:
             cur = torch.cuda.current_stream(p.device)
             if all(cur != s for s in b.streams):
                 b.streams.append(cur)
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0 and self.active:
             if p.is_cuda:
-                cur = torch.cuda.current_stream(p.device)
-                for s in b.streams:
-                    if s != cur:
-                        cur.wait_stream(s)
-            op = dist.ReduceOp.SUM
-            b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+                # Launch from a side stream that waits for every producer: ProcessGroupNCCL orders its own stream after the
+                # stream that is current at the call, so calling from a compute stream would first have to JOIN the model's
+                # streams there (wait_stream) and stall whichever is ahead, once per bucket, in the middle of backward.
+                ls = self._launch_stream(p.device)
+                for s_ in b.streams:
+                    ls.wait_stream(s_)
+                with torch.cuda.stream(ls):
+                    b.handle = dist.all_reduce(b.flat, op=self._op(), group=self.group, async_op=True)
+            else:
+                b.handle = dist.all_reduce(b.flat, op=self._op(), group=self.group, async_op=True)
+
+    def _launch_stream(self, device):
+        key = (device.type, device.index)
+        if key not in self._launch_streams:
+            self._launch_streams[key] = torch.cuda.Stream(device=device)
+        return self._launch_streams[key]
+
+    def _op(self):
+        return dist.ReduceOp.AVG if self.fused_avg else dist.ReduceOp.SUM
 
     def wait(self):
         """join the outstanding all-reduces (parameters that received no gradient this step still get
         their bucket reduced here) and apply the 1/world average"""
         for b in self.buckets:
-            if self.world > 1:
+            if self.active:
                 if b.handle is None:
-                    b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b.handle = dist.all_reduce(b.flat, op=self._op(), group=self.group, async_op=True)
                 b.handle.wait()
-                if self.average:
+                if self.average and not self.fused_avg:
                     b.flat.mul_(1.0 / self.world)
 
     @property

@@ -88,3 +88,55 @@ def test_train_step_learns_and_refreshes_weight_copies(dev):
     m2.compute_dtype = torch.bfloat16
     m2.load_state_dict(m.state_dict())
     assert torch.equal(m2(ids, img, mask), m(ids, img, mask))
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MEANT_REPO"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import meant_amd
+from meant_amd.parallel import GradReducer
+from meant_amd.train import cross_entropy_on_probs
+torch.manual_seed(0)
+model = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2).cuda().eval()
+model.compute_dtype = torch.bfloat16
+tw = torch.randint(0, 100, (4, 3, 16), device="cuda"); im = torch.randn(4, 3, 4, 32, 32, device="cuda")
+mask = torch.ones(4, 3, 16, device="cuda"); tgt = torch.randint(0, 2, (4,), device="cuda")
+def grads(always):
+    os.environ["MEANT_REDUCE_ALWAYS"] = "1" if always else "0"
+    for p in model.parameters():
+        p.grad = None
+    red = GradReducer(model.parameters(), bucket_mb=0.05)
+    assert red.active == always and red.fused_avg
+    red.prepare()
+    cross_entropy_on_probs(model(tw, im, mask), tgt).backward()
+    if always:
+        assert any(b.handle is not None for b in red.buckets), "no collective was launched from the hooks"
+    red.wait()
+    torch.cuda.synchronize()
+    return [p.grad.clone() for p in model.parameters() if p.grad is not None], red.num_buckets
+g1, nb = grads(True)
+g0, _ = grads(False)
+assert nb > 1
+for a, b in zip(g1, g0):
+    # (not bit-equal: the dW kernels accumulate with floating-point atomics, two backward passes differ in the last bits)
+    assert (a - b).abs().max().item() <= 1e-3 * max(b.abs().max().item(), 1e-6), "a one-rank average must be the identity"
+x = torch.arange(8, device="cuda", dtype=torch.float32)
+dist.all_reduce(x, op=dist.ReduceOp.AVG); assert torch.equal(x.cpu(), torch.arange(8, dtype=torch.float32))
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK", nb)
+"""
+
+
+def test_grad_reducer_over_rccl_one_rank(dev):
+    """the real RCCL call sequence (async all-reduce with ncclAvg from autograd hooks, two-stream ordering, wait) on a
+    one-rank group: the only part of the multi-GPU path a one-GPU box can run for real; in a child process so that the
+    process group does not leak into the other tests"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MEANT_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
