@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-per-gpu", type=int, default=128)
     ap.add_argument("--encoders", type=int, default=1)
+    ap.add_argument("--heads", type=int, default=12, help="attention heads (12 = BASELINE.json; 8 = the reference classes' default, head dim 96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity-mode numerics)")
     ap.add_argument("--two-streams", type=int, default=-1, help="override meant_amd.modules.TWO_STREAMS (0/1)")
@@ -200,6 +201,8 @@ def main():
                     help="also time the step fed by meant_amd.data.DeviceBatchLoader from host arrays of this pixel type "
                          "(PCIe-inclusive secondary figure, never `value`)")
     args = ap.parse_args()
+    global H
+    H = args.heads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -360,7 +363,7 @@ def main():
         res = {"metric": "samples/sec fwd+bwd, MEANT lag=12 d=768", "value": round(sps, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "full MEANT (tweet+image) fwd+CE+bwd, lag=12, d=768, 12 heads, seq=512, 224x224 p=16, "
+               "config": {"workload": f"full MEANT (tweet+image) fwd+CE+bwd, lag=12, d=768, {H} heads, seq=512, 224x224 p=16, "
                                       f"E={E}, vocab 64001 (BASELINE.json configs[2]/[3])",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                           "train_mode_dropout": not args.eval_mode, "activation_checkpointing": bool(args.checkpoint), "grad_allreduce": reducer.active,

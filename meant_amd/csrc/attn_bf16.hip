@@ -1,4 +1,4 @@
-// K3/K4: fused (flash-style) attention core for the bf16 tier, head dim 64, gfx950 MFMA 32x32x16.
+// K3/K4: fused (flash-style) attention core for the bf16 tier, head dims 64 and 128, gfx950 MFMA 32x32x16.
 // Replaces the reference's eager scores->softmax->PV chain (meant/attention.py:43-57,
 // meant/xPosAttention.py:41-63) and its flash-attn dependency (meant/flash_attention.py:42,
 // meant/xPosAttention_flash.py:40) with eager semantics: scale 1/sqrt(dim), causal -inf, additive
@@ -442,19 +442,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_persist_kernel(FwdArgs a) {
 // forward, one work item per workgroup: the form used without a causal mask, where every item has the same number of
 // tiles and the hardware's dynamic dispatch balances better than a fixed walk (measured: the persistent kernel is
 // 6-11 % slower there and 16-22 % faster under the causal mask, where items are 1-8 tiles long).
+template <int NH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [K0 | V0 | K1 | V1] 32 KiB, then bias[2][64] floats, then 4 per-wave patches of 32x144 B
-  float* bias_s = reinterpret_cast<float*>(smem + 4 * TILE_B);
-  char* patches = smem + 4 * TILE_B + 2 * 64 * 4;
+  // two buffers of [K: NH sub-tiles | V: NH sub-tiles] (a sub-tile = 64 keys x 64 of the head's 64 NH columns), then
+  // bias[2][64] floats, then 4 per-wave patches of 32x144 B (NH = 2: the patches reuse the tile space after the loop)
+  constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;
+  float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_B);
+  char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 64 * 4 : smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = a.S, H = a.H, D = H * DH;
+  const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
   const int g = blockIdx.z, h = blockIdx.y;
   // heaviest (latest) query blocks first under the causal mask
   const int qb = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
   const int q0 = qb * 128 + wave * 32;             // this wave's first query
-  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
   const bf16* Kg = base + D;
   const bf16* Vg = base + 2 * D;
   const int ntile = (S + KV_TILE - 1) / KV_TILE;
@@ -465,20 +468,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   // tile is requested before anything else: its round trip is the longest link of the workgroup's start-up chain.
   const StageOff soff = make_stage_off(ld, S, wave, lane);
   auto stage = [&](int t, int buf) {
-    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
-    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+      stage64(Kg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, soff);
+      stage64(Vg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff);
+    }
     if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   stage(0, 0);
 
   // Q fragments (B operand): lane (query = lane&31, half) holds Q[q][16ks + 8*half .. +7]
-  bf16x8 qf[4];
+  bf16x8 qf[4 * NH];
   {
     int qrow = q0 + (lane & 31);
     qrow = qrow < S ? qrow : S - 1;
     const bf16* qp = base + (int64_t)qrow * ld + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    for (int ks = 0; ks < 4 * NH; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
   const int myq = q0 + (lane & 31);
 
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   };
   while (nt > 1 && (tile_flag(nt - 1) & 2)) --nt;    // trailing all-padding tiles contribute exactly 0
 
-  f32x16 oacc[2];
+  f32x16 oacc[2 * NH];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 2 * NH; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[b][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
@@ -513,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
     const int flag = tile_flag(t);
     const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));   // wave-uniform: tile not entirely above the diagonal / all padding
     if (active && q0 < S) {
-      const char* Kt = smem + buf * 2 * TILE_B;
-      const char* Vt = Kt + TILE_B;
+      const char* Kt = smem + buf * BUF_B;
+      const char* Vt = Kt + NH * TILE_B;
       // S^T (2 sub-tiles of 32 keys)
       f32x16 sacc[2];
 #pragma unroll
@@ -522,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[sb][e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc[sb], 0, 0, 0);
+        for (int ks = 0; ks < 4 * NH; ++ks)
+          sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt + (ks >> 2) * TILE_B, 32 * sb, ks & 3, lane), qf[ks], sacc[sb], 0, 0, 0);
       }
       // softmax in the log2 domain: t = s * (scale*log2e) (+ bias), p = exp2(t - m).  Tiles that touch neither the
       // diagonal, nor padding, nor the end of the sequence (most of them) take the mask-free path: one multiply and
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
         l_run *= alpha;
         m_run = m_new;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2 * NH; ++b)
 #pragma unroll
           for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
       }
@@ -584,19 +590,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
       const unsigned vaddr = lds_addr(Vt);
       auto pv = [&](auto SB) {
         constexpr int sb = decltype(SB)::value;
-        u32x2 lo[2][2], hi[2][2];
-        tr_issue<32 * sb>(vaddr, troff, 0, lo[0][0], hi[0][0]);
-        tr_issue<32 * sb>(vaddr, troff, 1, lo[0][1], hi[0][1]);
-        tr_issue<32 * sb + 16>(vaddr, troff, 0, lo[1][0], hi[1][0]);
-        tr_issue<32 * sb + 16>(vaddr, troff, 1, lo[1][1], hi[1][1]);
         bf16x8 pf[2];
         acc_to_frags(sacc[sb], pf[0], pf[1]);
-        lds_wait_all();
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int hf = 0; hf < NH; ++hf) {
+          u32x2 lo[2][2], hi[2][2];
+          tr_issue<32 * sb>(vaddr + hf * TILE_B, troff, 0, lo[0][0], hi[0][0]);
+          tr_issue<32 * sb>(vaddr + hf * TILE_B, troff, 1, lo[0][1], hi[0][1]);
+          tr_issue<32 * sb + 16>(vaddr + hf * TILE_B, troff, 0, lo[1][0], hi[1][0]);
+          tr_issue<32 * sb + 16>(vaddr + hf * TILE_B, troff, 1, lo[1][1], hi[1][1]);
+          lds_wait_all();
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), pf[s2], oacc[b], 0, 0, 0);
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              oacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), pf[s2], oacc[2 * hf + b], 0, 0, 0);
+        }
       };
       pv(std::integral_constant<int, 0>{});
       pv(std::integral_constant<int, 1>{});
@@ -613,10 +622,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   }
   // 1/l differs per lane (query): scale per lane, then transpose through the wave's LDS patch
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 2 * NH; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[b][e] *= inv_l;
-  store_transposed(oacc, 1.0f, patches + wave * (32 * 144), a.o + (int64_t)g * S * D + h * DH, D, q0, S, lane);
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) {
+    if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    store_transposed(reinterpret_cast<const f32x16(&)[2]>(oacc[2 * hf]), 1.0f, patches + wave * (32 * 144),
+                     a.o + (int64_t)g * S * D + h * HD + DH * hf, D, q0, S, lane);
+  }
 }
 
 
@@ -629,17 +643,19 @@ struct BwdArgs {
   RotTables rot;                                     // adjoint rotary on dq / dk when rot.qa != null
 };
 
+template <int NH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* bias_s = reinterpret_cast<float*>(smem + 4 * TILE_B);
-  char* patches = smem + 4 * TILE_B + 2 * 64 * 4;
+  constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;    // as in the forward
+  float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_B);
+  char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 64 * 4 : smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = a.S, H = a.H, D = H * DH;
+  const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
   const int g = blockIdx.z, h = blockIdx.y;
   const int qb = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
   const int q0 = qb * 128 + wave * 32;
-  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
   const bf16* Kg = base + D;
   const bf16* Vg = base + 2 * D;
   const int ntile = (S + KV_TILE - 1) / KV_TILE;
@@ -652,20 +668,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   // tile is requested before anything else: its round trip is the longest link of the workgroup's start-up chain.
   const StageOff soff = make_stage_off(ld, S, wave, lane);
   auto stage = [&](int t, int buf) {
-    stage64(Kg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
-    stage64(Vg, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+      stage64(Kg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, soff);
+      stage64(Vg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff);
+    }
     if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   stage(0, 0);
 
-  bf16x8 qf[4], dof[4];
+  bf16x8 qf[4 * NH], dof[4 * NH];
   float delta = 0.f;
   {
     const bf16* qp = base + (int64_t)qrow * ld + 8 * (lane >> 5);
-    const bf16* dop = a.dout + ((int64_t)g * S + qrow) * D + h * DH + 8 * (lane >> 5);
-    const bf16* op = a.o + ((int64_t)g * S + qrow) * D + h * DH + 8 * (lane >> 5);
+    const bf16* dop = a.dout + ((int64_t)g * S + qrow) * D + h * HD + 8 * (lane >> 5);
+    const bf16* op = a.o + ((int64_t)g * S + qrow) * D + h * HD + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4 * NH; ++ks) {
       qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
       dof[ks] = *reinterpret_cast<const bf16x8*>(dop + 16 * ks);
       const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
@@ -698,9 +717,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   };
   while (nt > 1 && (tile_flag(nt - 1) & 2)) --nt;    // trailing all-padding tiles contribute exactly 0
 
-  f32x16 dqacc[2];
+  f32x16 dqacc[2 * NH];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 2 * NH; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[b][e] = 0.f;
 
@@ -713,8 +732,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     const int flag = tile_flag(t);
     const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));
     if (active && q0 < S) {
-      const char* Kt = smem + buf * 2 * TILE_B;
-      const char* Vt = Kt + TILE_B;
+      const char* Kt = smem + buf * BUF_B;
+      const char* Vt = Kt + NH * TILE_B;
       const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);
       const bool special = diag || (flag & 1);
       const unsigned kaddr = lds_addr(Kt);
@@ -724,9 +743,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vt, 32 * sb, ks, lane), dof[ks], dpacc, 0, 0, 0);
+        for (int ks = 0; ks < 4 * NH; ++ks) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt + (ks >> 2) * TILE_B, 32 * sb, ks & 3, lane), qf[ks], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vt + (ks >> 2) * TILE_B, 32 * sb, ks & 3, lane), dof[ks], dpacc, 0, 0, 0);
         }
         if (!special) {
 #pragma unroll
@@ -749,19 +768,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
             }
           }
         }
-        u32x2 lo[2][2], hi[2][2];
-        tr_issue<32 * sb>(kaddr, troff, 0, lo[0][0], hi[0][0]);
-        tr_issue<32 * sb>(kaddr, troff, 1, lo[0][1], hi[0][1]);
-        tr_issue<32 * sb + 16>(kaddr, troff, 0, lo[1][0], hi[1][0]);
-        tr_issue<32 * sb + 16>(kaddr, troff, 1, lo[1][1], hi[1][1]);
         bf16x8 dsf[2];
         acc_to_frags(sacc, dsf[0], dsf[1]);
-        lds_wait_all();
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int hf = 0; hf < NH; ++hf) {
+          u32x2 lo[2][2], hi[2][2];
+          tr_issue<32 * sb>(kaddr + hf * TILE_B, troff, 0, lo[0][0], hi[0][0]);
+          tr_issue<32 * sb>(kaddr + hf * TILE_B, troff, 1, lo[0][1], hi[0][1]);
+          tr_issue<32 * sb + 16>(kaddr + hf * TILE_B, troff, 0, lo[1][0], hi[1][0]);
+          tr_issue<32 * sb + 16>(kaddr + hf * TILE_B, troff, 1, lo[1][1], hi[1][1]);
+          lds_wait_all();
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            dqacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), dsf[s2], dqacc[b], 0, 0, 0);
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              dqacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), dsf[s2], dqacc[2 * hf + b], 0, 0, 0);
+        }
       };
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
@@ -769,36 +791,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     __syncthreads();
   }
   if (q0 >= S) return;
-  if (a.rot.qa) rotary_adjoint_regs(dqacc, a.rot.qa, a.rot.qb, a.rot.R, qrow, lane);
-  store_transposed(dqacc, a.scale, patches + wave * (32 * 144), a.dqkv + (int64_t)g * S * ld + h * DH, ld, q0, S, lane);
+  // rotary lanes are the first rot.R <= 64 columns of a head: the first half only
+  if (a.rot.qa) rotary_adjoint_regs(reinterpret_cast<f32x16(&)[2]>(dqacc[0]), a.rot.qa, a.rot.qb, a.rot.R, qrow, lane);
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) {
+    if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    store_transposed(reinterpret_cast<const f32x16(&)[2]>(dqacc[2 * hf]), a.scale, patches + wave * (32 * 144),
+                     a.dqkv + (int64_t)g * S * ld + h * HD + DH * hf, ld, q0, S, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, pass 2: dK, dV.  workgroup = 4 waves x 32 keys; Q / dO tiles of 64 queries stream through LDS.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
+template <int NH>
+__global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [Q0 | dO0 | Q1 | dO1] 32 KiB, stats[2][3][64] floats, 4 patches
-  float* stats = reinterpret_cast<float*>(smem + 4 * TILE_B);
-  char* patches = smem + 4 * TILE_B + 2 * 3 * 64 * 4;
+  // two buffers of [Q: NH sub-tiles | dO: NH sub-tiles], stats[2][3][64] floats, 4 patches (NH = 2: in the tile space)
+  constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;
+  float* stats = reinterpret_cast<float*>(smem + 2 * BUF_B);
+  char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 3 * 64 * 4 : smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = a.S, H = a.H, D = H * DH;
+  const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
   const int g = blockIdx.z, h = blockIdx.y;
   const int kb0 = blockIdx.x * 128;                  // block's first key
   const int key0 = kb0 + wave * 32;                  // wave's first key
   const int mykey = key0 + (lane & 31);
   const int krow = mykey < S ? mykey : S - 1;
-  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;
-  const bf16* dO = a.dout + (int64_t)g * S * D + h * DH;
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
+  const bf16* dO = a.dout + (int64_t)g * S * D + h * HD;
   const float* lse = a.lse + ((int64_t)g * H + h) * S * 2;
   const float* dl = a.delta + ((int64_t)g * H + h) * S;
 
-  bf16x8 kf[4], vf[4];
+  bf16x8 kf[4 * NH], vf[4 * NH];
   {
     const bf16* kp = base + (int64_t)krow * ld + D + 8 * (lane >> 5);
     const bf16* vp = base + (int64_t)krow * ld + 2 * D + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4 * NH; ++ks) {
       kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
       vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
     }
@@ -807,9 +837,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
   const int ntile = (S + KV_TILE - 1) / KV_TILE;
   const float bkey = mykey < ntile * KV_TILE ? a.bias2[(int64_t)g * ntile * KV_TILE + mykey] : -INFINITY;   // key bias (log2 units; -inf past S)
 
-  f32x16 dkacc[2], dvacc[2];
+  f32x16 dkacc[2 * NH], dvacc[2 * NH];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 2 * NH; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dkacc[b][e] = 0.f; dvacc[b][e] = 0.f; }
 
@@ -833,8 +863,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
   // per-tile statistics by DMA too: st[0..127] = interleaved (m, log l) pairs of the 64 queries, st[128..191] = delta
   const StageOff soff_q = make_stage_off(ld, S, wave, lane), soff_do = make_stage_off(D, S, wave, lane);
   auto stage = [&](int t, int buf) {
-    stage64(base, ld, t * 64, S, smem + buf * 2 * TILE_B, wave, lane, soff_q);
-    stage64(dO, D, t * 64, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff_do);
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+      stage64(base + DH * hf, ld, t * 64, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, soff_q);
+      stage64(dO + DH * hf, D, t * 64, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff_do);
+    }
     if (wave == 0) {
       float* st = stats + buf * 192;
       const int last = 2 * S - 1;
@@ -859,8 +892,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     const int qt0 = t * 64;
     const bool active = (key0 < S) && !wave_dead && (!a.causal || (qt0 + 63 >= key0));
     if (active) {
-      const char* Qt = smem + buf * 2 * TILE_B;
-      const char* dOt = Qt + TILE_B;
+      const char* Qt = smem + buf * BUF_B;
+      const char* dOt = Qt + NH * TILE_B;
       const float* st = stats + buf * 192;
       const unsigned qaddr = lds_addr(Qt), doaddr = lds_addr(dOt);
       auto body = [&](auto SQ) {
@@ -871,9 +904,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qt, 32 * sq, ks, lane), kf[ks], sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dOt, 32 * sq, ks, lane), vf[ks], dpacc, 0, 0, 0);
+        for (int ks = 0; ks < 4 * NH; ++ks) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qt + (ks >> 2) * TILE_B, 32 * sq, ks & 3, lane), kf[ks], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dOt + (ks >> 2) * TILE_B, 32 * sq, ks & 3, lane), vf[ks], dpacc, 0, 0, 0);
         }
         const bool diag = a.causal && (qs0 < key0 + 31);
         const bool tail = qs0 + 32 > S;
@@ -899,26 +932,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
             dpacc[e] = p * (dpacc[e] - dv[e4]);              // dS / scale
           }
         }
-        u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
-        tr_issue<32 * sq>(doaddr, troff, 0, dlo[0][0], dhi[0][0]);
-        tr_issue<32 * sq>(doaddr, troff, 1, dlo[0][1], dhi[0][1]);
-        tr_issue<32 * sq + 16>(doaddr, troff, 0, dlo[1][0], dhi[1][0]);
-        tr_issue<32 * sq + 16>(doaddr, troff, 1, dlo[1][1], dhi[1][1]);
-        tr_issue<32 * sq>(qaddr, troff, 0, qlo[0][0], qhi[0][0]);
-        tr_issue<32 * sq>(qaddr, troff, 1, qlo[0][1], qhi[0][1]);
-        tr_issue<32 * sq + 16>(qaddr, troff, 0, qlo[1][0], qhi[1][0]);
-        tr_issue<32 * sq + 16>(qaddr, troff, 1, qlo[1][1], qhi[1][1]);
         bf16x8 pf[2], dsf[2];
         acc_to_frags(sacc, pf[0], pf[1]);
         acc_to_frags(dpacc, dsf[0], dsf[1]);
-        lds_wait_all();
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int hf = 0; hf < NH; ++hf) {
+          u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
+          tr_issue<32 * sq>(doaddr + hf * TILE_B, troff, 0, dlo[0][0], dhi[0][0]);
+          tr_issue<32 * sq>(doaddr + hf * TILE_B, troff, 1, dlo[0][1], dhi[0][1]);
+          tr_issue<32 * sq + 16>(doaddr + hf * TILE_B, troff, 0, dlo[1][0], dhi[1][0]);
+          tr_issue<32 * sq + 16>(doaddr + hf * TILE_B, troff, 1, dlo[1][1], dhi[1][1]);
+          tr_issue<32 * sq>(qaddr + hf * TILE_B, troff, 0, qlo[0][0], qhi[0][0]);
+          tr_issue<32 * sq>(qaddr + hf * TILE_B, troff, 1, qlo[0][1], qhi[0][1]);
+          tr_issue<32 * sq + 16>(qaddr + hf * TILE_B, troff, 0, qlo[1][0], qhi[1][0]);
+          tr_issue<32 * sq + 16>(qaddr + hf * TILE_B, troff, 1, qlo[1][1], qhi[1][1]);
+          lds_wait_all();
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            dvacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[b], 0, 0, 0);
-            dkacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[b], 0, 0, 0);
-          }
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              dvacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[2 * hf + b], 0, 0, 0);
+              dkacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[2 * hf + b], 0, 0, 0);
+            }
+        }
       };
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
@@ -926,21 +962,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     __syncthreads();
   }
   if (key0 >= S) return;
-  if (a.rot.ka) rotary_adjoint_regs(dkacc, a.rot.ka, a.rot.kb, a.rot.R, krow, lane);
+  if (a.rot.ka) rotary_adjoint_regs(reinterpret_cast<f32x16(&)[2]>(dkacc[0]), a.rot.ka, a.rot.kb, a.rot.R, krow, lane);
   char* patch = patches + wave * (32 * 144);
-  store_transposed(dkacc, a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * DH, ld, key0, S, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  store_transposed(dvacc, 1.0f, patch, a.dqkv + (int64_t)g * S * ld + 2 * D + h * DH, ld, key0, S, lane);
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) {
+    if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    store_transposed(reinterpret_cast<const f32x16(&)[2]>(dkacc[2 * hf]), a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * HD + DH * hf,
+                     ld, key0, S, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    store_transposed(reinterpret_cast<const f32x16(&)[2]>(dvacc[2 * hf]), 1.0f, patch, a.dqkv + (int64_t)g * S * ld + 2 * D + h * HD + DH * hf,
+                     ld, key0, S, lane);
+  }
 }
 
 constexpr int BWD_DKV_LDS = 4 * TILE_B + 2 * 3 * 64 * 4 + 4 * 32 * 144;
 constexpr int FWD_LDS = 4 * TILE_B + 2 * 64 * 4 + 4 * 32 * 144;
+// head dim 128 (NH = 2): twice the tile space, the output patches live in it (2 workgroups per CU by LDS)
+constexpr int BWD_DKV_LDS2 = 8 * TILE_B + 2 * 3 * 64 * 4;
+constexpr int FWD_LDS2 = 8 * TILE_B + 2 * 64 * 4;
+__host__ inline bool native_dh(int Dh) { return Dh == DH || Dh == 2 * DH; }
 
 }  // namespace
 
-// Head dims other than 64 (e.g. the reference's default 8 heads -> Dh = 96) take a widening detour:
-// bf16 -> f32 copies in the workspace, the fp32 attention core, f32 -> bf16.  Correct for any Dh, not fast.
+// Head dims 64 and 128 run on the MFMA kernels above (128 as two 64-column halves of every tile).  The host side pads
+// other head dims below 128 up to 128 with zero columns (meant_amd/ops.py: the reference's default 8 heads -> Dh = 96),
+// so this is what they run on too.  Anything else handed to the C ABI directly takes a widening detour: bf16 -> f32
+// copies in the workspace, the fp32 attention core, f32 -> bf16.  Correct for any Dh, not fast.
 // workspace of the Dh=64 path: [delta: G*H*S floats | bias2: G*nt*64 floats | flags: G*nt ints | masks: G * 2 u64]
 static size_t ws_delta_bytes(int64_t G, int64_t S, int H) { return align256((size_t)G * H * S * sizeof(float)); }
 static size_t ws_bias_bytes(int64_t G, int64_t S) { return align256((size_t)G * ceil_div(S, KV_TILE) * KV_TILE * sizeof(float)); }
@@ -948,7 +996,7 @@ static size_t ws_flag_bytes(int64_t G, int64_t S) { return align256((size_t)G * 
 static size_t ws_mask_bytes(int64_t G) { return align256((size_t)G * 2 * sizeof(uint64_t)); }
 
 size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh) {
-  if (Dh == DH) return ws_delta_bytes(G, S, H) + ws_bias_bytes(G, S) + ws_flag_bytes(G, S) + ws_mask_bytes(G);
+  if (native_dh(Dh)) return ws_delta_bytes(G, S, H) + ws_bias_bytes(G, S) + ws_flag_bytes(G, S) + ws_mask_bytes(G);
   const size_t T = (size_t)G * S, D = (size_t)H * Dh;
   return 2 * align256(T * 3 * D * 4) + 2 * align256(T * D * 4) + attn_f32_ws(G, S, H, Dh);
 }
@@ -987,7 +1035,7 @@ static int attn_bf16_check(const char* name, int64_t G, int64_t S, int H, int Dh
 
 int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh, float scale,
                   int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (Dh != DH) return attn_bf16_generic(false, qkv, nullptr, nullptr, o, lse, key_mask, nullptr, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
+  if (!native_dh(Dh)) return attn_bf16_generic(false, qkv, nullptr, nullptr, o, lse, key_mask, nullptr, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
   int rc = attn_bf16_check("attn_fwd", G, S, H, Dh);
   if (rc) return rc;
   MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o), MEANT_ERR_ARG, "attn_fwd: 16-byte alignment");
@@ -1007,9 +1055,15 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   FwdArgs a{qkv, o, lse, bias2, flags, masks, (int)S, H, scale, causal, (int)G, nqb};
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS2);
     (void)hipFuncSetAttribute((const void*)attn_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
     attr_set = true;
+  }
+  if (Dh == 2 * DH) {
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS2, stream, a);
+    MEANT_LAUNCH_CHECK("attn_fwd");
+    return MEANT_OK;
   }
   static const int persist = getenv("MEANT_ATTN_PERSIST") ? atoi(getenv("MEANT_ATTN_PERSIST")) : -1;   // -1: causal only
   if (persist == 1 || (persist == -1 && causal)) {
@@ -1018,7 +1072,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
     const int64_t cap = (int64_t)meant_num_cus() * 3;
     hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), FWD_LDS, stream, a);
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
   }
   MEANT_LAUNCH_CHECK("attn_fwd");
   return MEANT_OK;
@@ -1026,7 +1080,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
 
 int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv, int64_t G,
                   int64_t S, int H, int Dh, float scale, int causal, RotTables rot, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (Dh != DH) {
+  if (!native_dh(Dh)) {
     int rcg = attn_bf16_generic(true, qkv, o, dout, nullptr, const_cast<float*>(lse), key_mask, dqkv, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
     if (rcg || !rot.qa) return rcg;
     return meant_rotary_qk(dqkv, G * S, S, H, Dh, rot.R, rot.qa, rot.qb, rot.ka, rot.kb, 1, MEANT_BF16, stream);
@@ -1051,14 +1105,23 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
   BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, (int)S, H, scale, causal, rot};
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DKV_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DKV_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS2);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DKV_LDS2);
     attr_set = true;
   }
   const dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), FWD_LDS, stream, a);
+  if (Dh == 2 * DH) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(256), FWD_LDS2, stream, a);
+    MEANT_LAUNCH_CHECK("attn_bwd_dq");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid, dim3(256), BWD_DKV_LDS2, stream, a);
+    MEANT_LAUNCH_CHECK("attn_bwd_dkv");
+    return MEANT_OK;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(256), FWD_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd_dq");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), BWD_DKV_LDS, stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(256), BWD_DKV_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd_dkv");
   return MEANT_OK;
 }

@@ -387,7 +387,7 @@ class _QKVAttention(torch.autograd.Function):
     weight of _ComposeLinear.  tables = (qa, qb, ka, kb) float [S, R] or None."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, bqkv, tables, key_mask, causal, num_heads):
+    def forward(ctx, x, wqkv, bqkv, tables, key_mask, causal, num_heads, scale=None):
         _need_gpu(x, wqkv)
         G, S, d = x.shape
         D = wqkv.shape[0] // 3
@@ -405,7 +405,7 @@ class _QKVAttention(torch.autograd.Function):
         o = torch.empty((G * S, D), device=x.device, dtype=x.dtype)
         lse = torch.empty((G, num_heads, S, 2), device=x.device, dtype=torch.float32)
         km = _c(key_mask.float()) if key_mask is not None else None
-        scale = 1.0 / math.sqrt(Dh * num_heads)
+        scale = 1.0 / math.sqrt(Dh * num_heads) if scale is None else float(scale)
         wsb = lib.meant_attn_ws(G, S, num_heads, Dh, dt)
         ws = torch.empty(max(wsb, 16), device=x.device, dtype=torch.uint8)
         check(lib.meant_attn_fwd(_p(qkv), _p(o), _p(lse), _p(km), G, S, num_heads, Dh, scale, int(causal), dt, _p(ws), wsb,
@@ -439,15 +439,33 @@ class _QKVAttention(torch.autograd.Function):
         dw = torch.zeros((N, K), device=do2.device, dtype=torch.float32)
         db = torch.zeros(N, device=do2.device, dtype=torch.float32)
         check(lib.meant_linear_bwd_dw(_p(dqkv), N, _p(x2), x2.stride(0), _p(dw), _p(db), M, N, K, dt, _stream()), "linear_bwd_dw")
-        return (dx.view(G, S, d) if dx is not None else None), dw, db, None, None, None, None
+        return (dx.view(G, S, d) if dx is not None else None), dw, db, None, None, None, None, None
+
+
+NATIVE_HEAD_DIMS = (64, 128)       # what the bf16 MFMA attention kernels take (csrc/attn_bf16.hip)
 
 
 def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads, pre=None):
-    """pre = (W1, b1) of a Linear applied to x immediately before the projections (composed into them)."""
+    """pre = (W1, b1) of a Linear applied to x immediately before the projections (composed into them).
+
+    bf16 tier, head dims other than 64 / 128 (the reference classes default to 8 heads: 96 at d = 768): every head is
+    widened to 128 columns by zero rows in the projection weights, so q, k, v come out of the GEMM already padded, the
+    scores are unchanged (zeros add nothing to q.k, the scale stays 1/sqrt(dim)), and the zero columns of v give zero
+    columns of the output, which are dropped again.  The padding is built from the parameters with differentiable ops,
+    so their gradients need no special handling."""
     wqkv = torch.cat([wq, wk, wv], dim=0)
     bqkv = torch.cat([bq, bk, bv], dim=0)
     if pre is not None:
         wqkv, bqkv = compose_linear(pre[0], pre[1], wqkv, bqkv)
+    D = wqkv.shape[0] // 3
+    Dh = D // num_heads
+    if x.dtype == torch.bfloat16 and Dh not in NATIVE_HEAD_DIMS and Dh < 128 and Dh % 8 == 0:
+        Dp, d = 128, wqkv.shape[1]
+        wp = torch.nn.functional.pad(wqkv.view(3 * num_heads, Dh, d), (0, 0, 0, Dp - Dh)).reshape(3 * num_heads * Dp, d)
+        bp = torch.nn.functional.pad(bqkv.view(3 * num_heads, Dh), (0, Dp - Dh)).reshape(3 * num_heads * Dp)
+        o = _QKVAttention.apply(x, wp, bp, tables, key_mask, causal, num_heads, 1.0 / math.sqrt(D))
+        G, S = o.shape[0], o.shape[1]
+        return o.view(G, S, num_heads, Dp)[..., :Dh].reshape(G, S, D)
     return _QKVAttention.apply(x, wqkv, bqkv, tables, key_mask, causal, num_heads)
 
 

@@ -228,7 +228,11 @@ def test_attention_modules_golden(M, O, dev, golden, dtype, name, kind):
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("kind,G,S,H,d", [("pixel", 3, 196, 12, 768), ("xpos", 2, 512, 12, 768), ("xpos", 5, 64, 2, 128),
                                           ("pixel", 2, 4, 2, 128), ("xpos", 3, 100, 4, 256), ("xpos", 2, 1, 2, 128),
-                                          ("pixel", 1, 300, 2, 128)])
+                                          ("pixel", 1, 300, 2, 128),
+                                          # head dims 96 (the reference's default 8 heads; padded to 128 in the bf16 tier),
+                                          # 128 (native), 80 (padded)
+                                          ("xpos", 2, 512, 8, 768), ("pixel", 3, 196, 8, 768), ("xpos", 3, 200, 2, 256),
+                                          ("pixel", 2, 130, 1, 128), ("xpos", 2, 100, 4, 320)])
 def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
     """real head geometry incl. ragged lengths (not multiples of any tile), S=1, fully padded rows"""
     ref, hip = _attn_pair(M, O, kind, H, d, dev)
@@ -253,10 +257,11 @@ def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-def test_text_attention_padding_patterns(M, O, dev, dtype):
+@pytest.mark.parametrize("H,d", [(2, 128), (2, 192), (1, 128)], ids=["dh64", "dh96", "dh128"])
+def test_text_attention_padding_patterns(M, O, dev, dtype, H, d):
     """the bf16 kernels skip key tiles that are all padding when key 0 is live; every pattern that does or does not
     qualify (suffix at and off tile boundaries, prefix, hole, one live key, nothing live) must match the oracle"""
-    G, S, H, d = 7, 320, 2, 128
+    G, S = 7, 320
     ref, hip = _attn_pair(M, O, "xpos", H, d, dev)
     rs = np.random.RandomState(99)
     x = t(rs.standard_normal((G, S, d)).astype("float32"))
