@@ -107,7 +107,9 @@ def test_meant_full_c3_golden(golden, dev, dtype):
     mask[1, :, 400:] = 0
     _, hip = _mk("meant", (768, 768, 4, 224, 224, 16, 12, 2), dict(num_heads=12, num_encoders=1), (2000, 768), dev)
     worst = _run_golden(g, hip, (ids, img, mask), dtype, dev)
-    print(f"full C3 [{dtype}]: worst grad-norm rel err {worst:.3e}")
+    with torch.no_grad():
+        err = (hip(ids.to(dev), img.to(dev), mask.to(dev)).cpu() - t(g["out"])).abs().max().item()
+    print(f"full C3 [{dtype}]: max |out - golden| {err:.3e}, worst grad-norm rel err {worst:.3e}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)

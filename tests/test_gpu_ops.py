@@ -311,8 +311,11 @@ def test_meanpool_patchify_embedding_rowvec(M, O, dev, dtype):
     a = t(rs.standard_normal((6, 37, 128)).astype("float32"))
     b = t(rs.standard_normal((6, 196, 256)).astype("float32"))
     ah, bh = a.to(dev).to(dtype).requires_grad_(), b.to(dev).to(dtype).requires_grad_()
-    out = ops.meanpool_cat(ah, bh)
     ref = torch.cat((a.to(dtype).float().mean(1), b.to(dtype).float().mean(1)), dim=1)
+    out = ops.meanpool_cat(ah, bh)                       # default: the pooled features stay in the tier's dtype
+    assert out.dtype == dtype
+    assert_close(out, ref, 1e-5 if dtype == torch.float32 else 4e-3, "meanpool")
+    out = ops._MeanPoolCat.apply(ah, bh, torch.float32)  # fp32 tail (ops.TAIL_FP32)
     assert out.dtype == torch.float32
     assert_close(out, ref, 1e-5, "meanpool")
     w = torch.randn_like(out)

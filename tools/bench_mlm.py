@@ -12,7 +12,7 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--encoders", type=int, default=12)
-    ap.add_argument("--heads", type=int, default=12, help="12 -> Dh = 64 (flash path); the reference's default 8 -> Dh = 96 (widening fallback)")
+    ap.add_argument("--heads", type=int, default=12, help="12 -> Dh = 64 (flash path); the reference's default 8 -> Dh = 96 (zero-padded to the 128-wide kernels)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--steps", type=int, default=5)
