@@ -943,7 +943,9 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
     attr256_set = true;
   }
-  if (a.M >= 1024 && a.N % 256 == 0) {              // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP)
+  // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP) -- once there are enough of them to occupy at least
+  // half the CUs (the temporal encoder's 1536^2 Linears make 36: four times as many 128 x 128 tiles finish in a third of the time)
+  if (a.M >= 1024 && a.N % 256 == 0 && ceil_div(a.M, B2) * (a.N / B2) * 2 >= meant_num_cus()) {
     const int64_t ntm2 = ceil_div(a.M, B2), ntn2 = a.N / B2;
     MEANT_REQUIRE(ntm2 * ntn2 < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
     // MEANT_NT_STREAM=0 forces the one-tile-per-workgroup kernel (A/B measurements)
