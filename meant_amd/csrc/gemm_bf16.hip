@@ -521,7 +521,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       // Waves 4-7 issue no DMA: all they can have in flight are old output stores and the requests above.  In the three
       // steps of the draw they wait for everything (the stores are long gone by then).
       const bool sched_step = dynamic && !issuer && kt >= 3 && kt <= 5;
-      if (more2 && !sched_step && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      if ((DBG & 8) && !issuer && !sched_step) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lab: stores of waves 4-7 drain freely
+      else if (more2 && !sched_step && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       asm volatile("" : "+v"(mail), "+v"(ticket) : : "memory");
       // tile draw, part 2: the answers are here
@@ -619,7 +620,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[h][e] : hi[h][e - 4]) + bias[e];
-            nt_store_row8(a, m0 + wm * 128 + i * 16 + r, n, v, true);
+            if (DBG & 16) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])); }   // lab: everything but the global store
+            else nt_store_row8(a, m0 + wm * 128 + i * 16 + r, n, v, true);
           }
         } else {
           // finish both rows, THEN ask for the next round's tables (into the same registers), THEN store
