@@ -13,7 +13,7 @@ import torch
 
 
 def timeit(step, steps):
-    for _ in range(5):                                   # the first steps of a process also load code objects
+    for _ in range(10):                                  # the first steps of a process also load code objects and ramp the clocks
         loss = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -27,7 +27,7 @@ def timeit(step, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--heads", type=int, default=12)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     args = ap.parse_args()
     import meant_amd as M
     from meant_amd.train import cross_entropy_on_probs
