@@ -85,9 +85,13 @@ class GemmTimer:
             def __getattr__(self_, n):
                 return getattr(lib, n)
         proxy = LibProxy()
-        # the launches that gemm_bf16_nt_launch routes to gemm_bf16_nt256s_kernel: bf16, M >= 1024, M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128
+        # the launches that gemm_bf16_nt_launch routes to gemm_bf16_nt256s_kernel: bf16, M >= 1024, M % 256 == 0, N % 256 == 0,
+        # K % 64 == 0, K >= 128, and at least half a chip of 256 x 256 tiles (fewer go to the 128 x 128 kernel)
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+
         def nt256(M, N, K, dtype):
-            return 2.0 * M * N * K if (dtype == 1 and M >= 1024 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128) else 0.0
+            ok = dtype == 1 and M >= 1024 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128 and (M // 256) * (N // 256) * 2 >= ncu
+            return 2.0 * M * N * K if ok else 0.0
         # meant_linear_fwd(x, ldx, w, bias, res, ldr, y, ldy, pre, M, N, K, epi, dtype, stream)
         proxy.meant_linear_fwd = wrap("meant_linear_fwd", lambda a: nt256(a[9], a[10], a[11], a[13]),
                                       lambda a: (a[9], a[10], a[11], 2.0 * a[9] * a[10] * ((1 if a[4] else 0) + (1 if a[8] else 0))))

@@ -387,3 +387,17 @@ def test_activation_checkpointing_same_gradients(dev):
     for k, g0 in res[0][1].items():
         g1 = res[1][1][k]
         assert (g0 - g1).abs().max().item() <= 1e-5 * max(1.0, g0.abs().max().item()), k
+
+
+def test_fp32_tail_switch(golden, dev, monkeypatch):
+    """ops.TAIL_FP32 = True keeps the temporal encoder and the head in fp32 inside the bf16 tier (the default lets them follow
+    the tier): same gates, and the pooled features really are fp32"""
+    from meant_amd import ops
+    monkeypatch.setattr(ops, "TAIL_FP32", True)
+    a = torch.randn(2, 5, 128, device=dev, dtype=torch.bfloat16)
+    assert ops.meanpool_cat(a).dtype == torch.float32
+    g = golden("meant_tiny")
+    _, hip = _mk("meant", (128, 128, 4, 32, 32, 16, 3, 2), dict(num_heads=2, num_encoders=1, channels=4), (100, 128), dev)
+    _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), torch.bfloat16, dev)
+    monkeypatch.setattr(ops, "TAIL_FP32", False)
+    assert ops.meanpool_cat(a).dtype == torch.bfloat16
