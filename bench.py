@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity-mode numerics)")
     ap.add_argument("--two-streams", type=int, default=-1, help="override meant_amd.modules.TWO_STREAMS (0/1)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time the step with clip + fused AdamW (extra field)")
+    ap.add_argument("--forward-only", action="store_true", help="also time the eval-mode forward alone (serving-style secondary figure)")
     ap.add_argument("--checkpoint", action="store_true", help="model.activation_checkpointing = True (needed for --encoders 12 at 128 samples)")
     ap.add_argument("--from-host", choices=["f64", "f32", "u8"], default=None,
                     help="also time the step fed by meant_amd.data.DeviceBatchLoader from host arrays of this pixel type "
@@ -308,6 +309,23 @@ def main():
         barrier()
         opt_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
+    # secondary figure: the eval-mode forward alone (what a deployment that only scores runs)
+    fwd_ms = None
+    if args.forward_only:
+        was_training = model.training
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(tweets, images, mask)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model(tweets, images, mask)
+            barrier()
+            fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        assert torch.isfinite(out).all().item()
+        model.train(was_training)
+
     # secondary figure: the same step fed from HOST arrays in the data set's storage type through the double-buffered
     # loader (gather into pinned memory, H2D on its own stream, conversion + normalisation + patchify on the device)
     host_ms = None
@@ -374,6 +392,9 @@ def main():
                           "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1),
                           "gflop_per_sample_executed": round(flops_per_sample_executed(E) / 1e9, 1)},
                "roofline": roofline}
+        if fwd_ms is not None:
+            res["forward_only"] = {"ms_per_step": round(fwd_ms, 3), "samples_per_s": round(world * B / fwd_ms * 1e3, 2),
+                                   "what": "eval-mode forward under no_grad, same batch"}
         if opt_ms is not None:
             res["with_optimizer"] = {"ms_per_step": round(opt_ms, 3), "samples_per_s": round(world * B / opt_ms * 1e3, 2),
                                      "what": "fwd+CE+bwd + global-norm clip(1.0) + fused AdamW on the flat fp32 buckets"}
