@@ -54,6 +54,33 @@ const char* meant_last_error(void);
 /* number of compute units of the current device (for sizing partial-sum workspaces) */
 int meant_num_cus(void);
 
+/* ---- process-wide switches and diagnostics --------------------------------------------------------
+ * The library keeps no mutable global state except: a per-device table filled on first use (CU count, raised LDS
+ * limits, the tile counters of the streaming GEMM -- one slot per (device, stream)), these options, and the
+ * route counters below.  All of it is safe to use from several host threads and with several devices in one
+ * process (the reference's nn.DataParallel, pretrain_mlm.py:329): every call acts on the calling thread's current
+ * device, whose memory all pointer arguments must belong to.
+ * Options (initial value from the environment variable MEANT_<NAME IN CAPITALS>):
+ *   "deterministic"    0|1   parameter gradients (dW, dbias) by ordered reductions instead of float atomics: two runs
+ *                            on the same inputs are bit-identical; meant_linear_bwd_dw then needs its workspace
+ *   "nt_stream"        1|0   streaming 256x256 NT GEMM / one tile per workgroup           (A/B measurements)
+ *   "nt_dynamic"       1|0   streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements)
+ *   "nt_qkv_split"     1|0   fused q|k|v projection as three L2-resident column passes / one pass
+ *   "nt_grid_cap"      0|n   cap the streaming GEMM's grid at n workgroups (tests: many tiles per workgroup, steals)
+ *   "attn_persist"    -1|0|1 persistent attention forward: causal only / never / always
+ *   "attn_bwd_persist" 1|0   persistent attention backward kernels / one item per workgroup */
+int meant_set_option(const char* name, int value);
+int meant_get_option(const char* name, int* value);
+/* how many launches took a given kernel route since the last reset ("nt128", "nt256", "nt256s", "nt256s_rot",
+ * "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32", "attn_fwd", "attn_fwd_persist", "attn_fwd_d128",
+ * "attn_fwd_d96", "attn_bwd", "attn_bwd_persist", "attn_bwd_d128", "attn_bwd_d96", "attn_generic", "attn_cls");
+ * -1 for an unknown name.  Tests use it to prove that a shape reaches the kernel it is meant to exercise. */
+int64_t meant_route_count(const char* route);
+void meant_route_reset(void);
+/* tiles the streaming GEMM's workgroups took from another XCD's counter, summed over all launches on the current
+ * device so far; synchronises the device (test diagnostics) */
+int64_t meant_debug_nt_steals(void);
+
 /* ---- RMSNorm ---------------------------------------------------- utils/rms_norm.py:40-57
  * y = scale * x * rinv,  rinv = 1 / (||x||_2 / sqrt(d) + eps)   (eps outside the sqrt)
  * x,y: act [rows, d]; scale: float [d]; rinv: float [rows] (saved for backward).
@@ -96,9 +123,13 @@ int meant_qkv_proj_fwd(const void* x, int64_t ldx, const void* w, const float* b
 int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, int64_t M,
                         int64_t N, int64_t K, int dtype, void* stream);
 /* dw[N,K] += dy[M,N]^T x[M,K]  and  dbias[N] += colsum(dy)  -- float accumulators the caller zeroes
- * (or pre-loads to accumulate across micro-batches).  dbias may be NULL. */
+ * (or pre-loads: gradient buckets, accumulation across micro-batches).  dbias may be NULL.
+ * workspace: meant_linear_bwd_dw_ws(M, N, K, dtype) bytes (0 unless the "deterministic" option is on: then the
+ * per-workgroup partial sums go there and are added up in a fixed order); NULL / 0 otherwise. */
+size_t meant_linear_bwd_dw_ws(int64_t M, int64_t N, int64_t K, int dtype);
 int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias,
-                        int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+                        int64_t M, int64_t N, int64_t K, int dtype, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* generic strided batched GEMM, float storage, f32 MFMA (exact fp32 products):
  * C[b1,b2][m,n] = alpha * sum_k A[b1,b2](m,k) * B[b1,b2](k,n)   (+ C if accumulate)
@@ -203,7 +234,8 @@ int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorted_ids, cons
 
 /* ---- train-step tail ------------------------------------------- in_loop_train.py:232-238,547-548
  * CrossEntropyLoss (mean) applied to the model's probabilities [B, C] as the reference does: loss_accum[0] +=
- * loss (caller zeroes it), dprobs (optional) receives d loss / d probs. */
+ * loss (caller zeroes it), dprobs (optional) receives d loss / d probs.  A target outside [0, C) turns the loss and
+ * that row of dprobs into NaN (no out-of-bounds access). */
 int meant_ce_probs(const float* probs, const int64_t* target, float* loss_accum, float* dprobs, int64_t B, int C,
                    void* stream);
 /* ---- large-vocabulary softmax cross-entropy (MLM pretrainer) ----------- pretrain_mlm.py:160,178

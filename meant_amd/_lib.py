@@ -30,7 +30,13 @@ SIGNATURES = {
     "meant_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _sz, _p]),
     "meant_linear_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p]),
     "meant_linear_bwd_dx": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
-    "meant_linear_bwd_dw": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "meant_linear_bwd_dw_ws": (_sz, [_i64, _i64, _i64, _i]),
+    "meant_linear_bwd_dw": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i, _p, _sz, _p]),
+    "meant_set_option": (_i, [C.c_char_p, _i]),
+    "meant_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
+    "meant_route_count": (_i64, [C.c_char_p]),
+    "meant_route_reset": (None, []),
+    "meant_debug_nt_steals": (_i64, []),
     "meant_gemm_f32_strided": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _f, _i, _p]),
     "meant_rotary_qk": (_i, [_p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
     "meant_attn_ws": (_sz, [_i64, _i64, _i, _i, _i]),
@@ -81,6 +87,27 @@ def _load():
 
 
 lib = _load()
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib.meant_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name: str) -> int:
+    v = _i(0)
+    check(lib.meant_get_option(name.encode(), C.byref(v)), "get_option")
+    return v.value
+
+
+def route_count(route: str) -> int:
+    n = lib.meant_route_count(route.encode())
+    if n < 0:
+        raise KeyError(route)
+    return n
+
+
+def route_reset() -> None:
+    lib.meant_route_reset()
 
 
 class MeantHipError(RuntimeError):

@@ -100,8 +100,12 @@ extern "C" int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT,
   return MEANT_ERR_ARG;
 }
 
+extern "C" size_t meant_linear_bwd_dw_ws(int64_t M, int64_t N, int64_t K, int dtype) {
+  return dtype == MEANT_BF16 ? gemm_bf16_tn_ws(M, N, K) : 0;
+}
+
 extern "C" int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias, int64_t M,
-                                   int64_t N, int64_t K, int dtype, void* stream) {
+                                   int64_t N, int64_t K, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   MEANT_REQUIRE(dy && x && dw, MEANT_ERR_ARG, "linear_bwd_dw: null pointer");
   MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K, MEANT_ERR_ARG, "linear_bwd_dw: bad shape");
   if (dtype == MEANT_F32) {
@@ -128,7 +132,7 @@ extern "C" int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, 
     return MEANT_OK;
   }
   if (dtype == MEANT_BF16)
-    return gemm_bf16_tn_launch((const bf16*)dy, lddy, (const bf16*)x, ldx, dw, dbias, M, N, K, (hipStream_t)stream);
+    return gemm_bf16_tn_launch((const bf16*)dy, lddy, (const bf16*)x, ldx, dw, dbias, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
   meant_set_error("linear_bwd_dw: unknown dtype %d", dtype);
   return MEANT_ERR_ARG;
 }

@@ -1006,6 +1006,7 @@ static int cast_async(const void* src, int sd, void* dst, int dd, int64_t n, hip
 static int attn_bf16_generic(bool backward, const bf16* qkv, const bf16* o, const bf16* dout, bf16* o_out, float* lse, const float* key_mask,
                              bf16* dqkv, int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes,
                              hipStream_t stream) {
+  meant_route_hit(ROUTE_ATTN_GENERIC);
   MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn(bf16, Dh=%d): workspace too small", Dh);
   const int64_t T = G * S, D = (int64_t)H * Dh;
   char* w = (char*)ws;
@@ -1053,25 +1054,24 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   }
   const int nqb = (int)ceil_div(S, 128);
   FwdArgs a{qkv, o, lse, bias2, flags, masks, (int)S, H, scale, causal, (int)G, nqb};
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS2);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    attr_set = true;
-  }
+  MEANT_RAISE_LDS(attn_fwd_kernel<1>, FWD_LDS);
+  MEANT_RAISE_LDS(attn_fwd_kernel<2>, FWD_LDS2);
+  MEANT_RAISE_LDS(attn_fwd_persist_kernel, FWD_LDS);
   if (Dh == 2 * DH) {
+    meant_route_hit(ROUTE_ATTN_FWD_D128);
     hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS2, stream, a);
     MEANT_LAUNCH_CHECK("attn_fwd");
     return MEANT_OK;
   }
-  static const int persist = getenv("MEANT_ATTN_PERSIST") ? atoi(getenv("MEANT_ATTN_PERSIST")) : -1;   // -1: causal only
+  const int persist = meant_opt(MEANT_OPT_ATTN_PERSIST);   // -1: causal only
   if (persist == 1 || (persist == -1 && causal)) {
+    meant_route_hit(ROUTE_ATTN_FWD_PERSIST);
     // persistent grid: as many workgroups as are resident at once (3 per CU by LDS and registers), never more than items
     const int64_t nitems = (int64_t)nqb * H * G;
     const int64_t cap = (int64_t)meant_num_cus() * 3;
     hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), FWD_LDS, stream, a);
   } else {
+    meant_route_hit(ROUTE_ATTN_FWD);
     hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
   }
   MEANT_LAUNCH_CHECK("attn_fwd");
@@ -1103,22 +1103,20 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     MEANT_LAUNCH_CHECK("attn_pack_flags");
   }
   BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, (int)S, H, scale, causal, rot};
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DKV_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS2);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DKV_LDS2);
-    attr_set = true;
-  }
+  MEANT_RAISE_LDS(attn_bwd_dq_kernel<1>, FWD_LDS);
+  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<1>, BWD_DKV_LDS);
+  MEANT_RAISE_LDS(attn_bwd_dq_kernel<2>, FWD_LDS2);
+  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<2>, BWD_DKV_LDS2);
   const dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
   if (Dh == 2 * DH) {
+    meant_route_hit(ROUTE_ATTN_BWD_D128);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(256), FWD_LDS2, stream, a);
     MEANT_LAUNCH_CHECK("attn_bwd_dq");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid, dim3(256), BWD_DKV_LDS2, stream, a);
     MEANT_LAUNCH_CHECK("attn_bwd_dkv");
     return MEANT_OK;
   }
+  meant_route_hit(ROUTE_ATTN_BWD);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(256), FWD_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd_dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(256), BWD_DKV_LDS, stream, a);

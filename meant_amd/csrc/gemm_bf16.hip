@@ -26,6 +26,8 @@
 #include "internal.h"
 #include <type_traits>
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
@@ -390,7 +392,8 @@ constexpr int RING = 5;
 struct alignas(64) TileSched {
   unsigned next[8];
   unsigned done;
-  unsigned pad[7];
+  unsigned steals;       // diagnostics: tiles taken from another XCD's counter (never reset by the kernel)
+  unsigned pad[6];
   unsigned mailbox[512];
 };
 constexpr int N_SCHED_SLOTS = 256;
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
             const int x2 = (xcd + att) & 7;
             if (tile_of(x2, (unsigned)CH + seen[x2]) >= ntiles) continue;
             id = tile_of(x2, (unsigned)CH + atomicAdd(&sched->next[x2], 1u));
+            if (id < ntiles) atomicAdd(&sched->steals, 1u);
           }
         }
         const unsigned pub = id < ntiles ? (unsigned)id : 0xffffffffu;
@@ -814,10 +818,15 @@ __device__ __forceinline__ void tn256_frag_issue(unsigned addr, u32x2& lo, u32x2
   hi = lds_read_tr16<KS * 8192 + 2048>(addr);
 }
 
+// DET: instead of float atomics on dW / dbias (whose order differs from run to run) every workgroup stores its 256 x 256 partial
+// tile to `part` [split][tile][256][256] and its bias partials to `pbias` [split][tk][wk][N]; tn256_reduce_kernel then adds them
+// up in a fixed order.  Same MFMA stream, so the partial sums themselves are bit-identical between runs.
+template <bool DET>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
                                                                   int64_t ldx, float* __restrict__ dW, float* __restrict__ dbias,
                                                                   int64_t M, int64_t N, int64_t K, int ntn, int ntk,
-                                                                  int64_t rows_per_split) {
+                                                                  int64_t rows_per_split, float* __restrict__ part,
+                                                                  float* __restrict__ pbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 2, wk = wave & 3;
@@ -909,27 +918,91 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
     compute(std::integral_constant<int, 3>{});
     __syncthreads();
   }
+  float* ptile = DET ? part + ((int64_t)split * (ntn * ntk) + tile) * 65536 : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int64_t kcol = k0 + wk * 64 + j * 32 + (lane & 31);
+      const int kl = wk * 64 + j * 32 + (lane & 31);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t nrow = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        atomicAdd(dW + nrow * K + kcol, acc[i][j][e]);
+        const int nl = wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (DET) ptile[nl * 256 + kl] = acc[i][j][e];
+        else atomicAdd(dW + (n0 + nl) * K + k0 + kl, acc[i][j][e]);
       }
     }
   if (do_bias) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float s2 = csum[i] + __shfl_xor(csum[i], 32, 64);
-      if (lane < 32) atomicAdd(dbias + n0 + wn * 128 + i * 32 + lane, s2);
+      if (lane < 32) {
+        const int64_t n = n0 + wn * 128 + i * 32 + lane;
+        if (DET) pbias[(((int64_t)split * ntk + tk) * 4 + wk) * N + n] = s2;
+        else atomicAdd(dbias + n, s2);
+      }
     }
   }
 }
 
+// ordered reduction of the deterministic dW path: dW[n][k] += sum_s part[s][tile(n,k)][n%256][k%256] (s ascending), and
+// dbias[n] += sum over (s, tk, wk) ascending of pbias.  One thread per 4 consecutive k.
+__global__ __launch_bounds__(256) void tn256_reduce_kernel(const float* __restrict__ part, const float* __restrict__ pbias,
+                                                            float* __restrict__ dW, float* __restrict__ dbias, int64_t N, int64_t K,
+                                                            int ntk, int ntiles, int splits) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nq = N * K / 4;
+  if (q < nq) {
+    const int64_t n = (q * 4) / K, k = (q * 4) % K;
+    const int64_t tile = (n >> 8) * ntk + (k >> 8);
+    const float* src = part + tile * 65536 + (n & 255) * 256 + (k & 255);
+    f32x4 s = *reinterpret_cast<const f32x4*>(src);
+    for (int sp = 1; sp < splits; ++sp) s += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * ntiles * 65536);
+    f32x4* dst = reinterpret_cast<f32x4*>(dW + n * K + k);
+    *dst = *dst + s;
+  }
+  if (dbias && q < N) {
+    float s = 0.f;
+    for (int i = 0; i < splits * ntk * 4; ++i) s += pbias[(int64_t)i * N + q];
+    dbias[q] += s;
+  }
+}
+
 }  // namespace
+
+// Scheduler slot of (current device, stream); nullptr when the table is full or the symbol cannot be resolved.
+// g_tile_sched is a __device__ array: every device has its own copy at its own address.
+static TileSched* tile_sched_for(hipStream_t stream) {
+  struct PerDevice { TileSched* base = nullptr; bool tried = false; std::unordered_map<hipStream_t, int> slot; };
+  static std::mutex mu;
+  static PerDevice table[MEANT_MAX_DEVICES];
+  const int dev = meant_current_device();
+  if (dev < 0) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  PerDevice& pd = table[dev];
+  if (!pd.tried) {
+    pd.tried = true;
+    if (hipGetSymbolAddress((void**)&pd.base, HIP_SYMBOL(g_tile_sched)) != hipSuccess) pd.base = nullptr;
+  }
+  if (!pd.base) return nullptr;
+  auto it = pd.slot.find(stream);
+  if (it != pd.slot.end()) return pd.base + it->second;
+  if ((int)pd.slot.size() >= N_SCHED_SLOTS) return nullptr;
+  const int idx = (int)pd.slot.size();
+  pd.slot.emplace(stream, idx);
+  return pd.base + idx;
+}
+
+// diagnostics for the tests: tiles that changed XCD in all streaming launches of the current device so far (synchronises)
+extern "C" int64_t meant_debug_nt_steals(void) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  static TileSched host[N_SCHED_SLOTS];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_sched), sizeof(host)) != hipSuccess) return -1;
+  int64_t n = 0;
+  for (int i = 0; i < N_SCHED_SLOTS; ++i) n += host[i].steals;
+  return n;
+}
 
 int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_REQUIRE(a.A && a.B && a.C, MEANT_ERR_ARG, "gemm_bf16_nt: null pointer");
@@ -938,20 +1011,16 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_REQUIRE(a.K % BK == 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: K=%lld must be a multiple of %d (use the fp32 tier otherwise)", (long long)a.K, BK);
   MEANT_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0 && meant_aligned16(a.A) && meant_aligned16(a.B), MEANT_ERR_ARG,
                 "gemm_bf16_nt: operands must be 16-byte aligned with row strides that are multiples of 8");
-  static bool attr256_set = false;
-  if (!attr256_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt256s_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * T2_BYTES);
-    attr256_set = true;
-  }
+  MEANT_RAISE_LDS(gemm_bf16_nt256_kernel, 4 * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, true>), RING * T2_BYTES);
   // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP) -- once there are enough of them to occupy at least
   // half the CUs (the temporal encoder's 1536^2 Linears make 36: four times as many 128 x 128 tiles finish in a third of the time)
   if (a.M >= 1024 && a.N % 256 == 0 && ceil_div(a.M, B2) * (a.N / B2) * 2 >= meant_num_cus()) {
     const int64_t ntm2 = ceil_div(a.M, B2), ntn2 = a.N / B2;
     MEANT_REQUIRE(ntm2 * ntn2 < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
-    // MEANT_NT_STREAM=0 forces the one-tile-per-workgroup kernel (A/B measurements)
-    static const bool stream_ok = !(getenv("MEANT_NT_STREAM") && atoi(getenv("MEANT_NT_STREAM")) == 0);
+    // option nt_stream = 0 forces the one-tile-per-workgroup kernel (A/B measurements)
+    const bool stream_ok = meant_opt(MEANT_OPT_NT_STREAM) != 0;
     // Ragged M: the streaming kernel takes the first floor(M / 256) * 256 rows, the remaining < 256 rows go to the
     // 128 x 128 kernel as a second launch (row-local epilogues only: the rotary epilogue indexes its tables by the
     // absolute row, so it splits only where the boundary is a multiple of the sequence length).
@@ -965,23 +1034,25 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       tail.C = a.C + m_full * a.ldc;
       if (a.residual) tail.residual = a.residual + m_full * a.ldr;
       if (a.preact) tail.preact = a.preact + m_full * a.ldc;
+      meant_route_hit(ROUTE_NT_SPLIT);
       const int rc = gemm_bf16_nt_launch(head, stream);
       return rc ? rc : gemm_bf16_nt_launch(tail, stream);
     }
     if (stream_ok && a.M % B2 == 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
-      const int ncu = meant_num_cus() & ~7;
+      int ncu = meant_num_cus() & ~7;
+      const int cap = meant_opt(MEANT_OPT_NT_GRID_CAP) & ~7;     // tests: fewer workgroups => more tiles each, dry XCDs steal
+      if (cap >= 8 && cap < ncu) ncu = cap;
       const int grid = (int)(ntm2 * ntn2 < ncu ? ((ntm2 * ntn2 + 7) / 8) * 8 : ncu);
-      // one scheduler slot per launch, handed out round-robin (a slot is free again once its launch has finished; 256
-      // launches later is far beyond anything the step keeps in flight).  MEANT_NT_DYNAMIC=0 falls back to the fixed walk.
-      static TileSched* sched_base = nullptr;
-      static std::atomic<unsigned> sched_next{0};
-      static const int dynmode = getenv("MEANT_NT_DYNAMIC") ? atoi(getenv("MEANT_NT_DYNAMIC")) : 1;
-      const bool dyn = dynmode != 0;
-      if (!sched_base) (void)hipGetSymbolAddress((void**)&sched_base, HIP_SYMBOL(g_tile_sched));
-      TileSched* sched = (dyn && sched_base && grid <= 512) ? sched_base + (sched_next.fetch_add(1) % N_SCHED_SLOTS) : nullptr;
+      // Tile counters: one slot per (device, stream).  Launches on one stream execute in order and a launch leaves its
+      // slot zeroed (last workgroup out), so a slot is never shared by two launches in flight -- by construction, not by
+      // distance.  A stream beyond the table's capacity gets the fixed walk (sched = nullptr).  Option nt_dynamic = 0 forces it.
+      const int dynmode = meant_opt(MEANT_OPT_NT_DYNAMIC);
+      TileSched* sched = (dynmode != 0 && grid <= 512) ? tile_sched_for(stream) : nullptr;
+      meant_route_hit(a.rot_qa ? ROUTE_NT256S_ROT : ROUTE_NT256S);
       if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
       else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
     } else {
+      meant_route_hit(ROUTE_NT256);
       hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);
     }
     MEANT_LAUNCH_CHECK("gemm_bf16_nt256");
@@ -990,11 +1061,8 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   const int64_t ntm = ceil_div(a.M, BM), ntn = ceil_div(a.N, BN);
   MEANT_REQUIRE(ntm * ntn < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
   const size_t lds = 128 * (128 + 4) * sizeof(float);   // 67584 B: covers the 64 KiB of staging buffers too
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  MEANT_RAISE_LDS(gemm_bf16_nt_kernel, lds);
+  meant_route_hit(ROUTE_NT128);
   hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(ntm * ntn)), dim3(256), lds, stream, a, (int)ntm, (int)ntn);
   MEANT_LAUNCH_CHECK("gemm_bf16_nt");
   return MEANT_OK;
@@ -1003,6 +1071,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
 static int tn_tail(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N, int64_t K,
                    hipStream_t stream) {
   // fewer than 64 trailing token rows: exact generic kernel, accumulating into the same dW / dbias
+  meant_route_hit(ROUTE_TN_TAIL);
   GemmF32Args g{};
   g.in_dtype = MEANT_BF16; g.out_dtype = MEANT_F32;
   g.A = dY; g.B = X; g.C = dW;
@@ -1015,8 +1084,34 @@ static int tn_tail(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, flo
   return MEANT_OK;
 }
 
+// launch geometry of the 256 x 256 dW kernel (shared by the launcher and the workspace query)
+static void tn256_geometry(int64_t M, int64_t N, int64_t K, int64_t& splits2, int64_t& rows2) {
+  // one resident block per CU: size the launch to whole rounds of the CU count (a lone block in an extra
+  // round would cost a full round of time) -- one round when every block still gets >= 32 tiles of 64 rows
+  int ncu = meant_num_cus();
+  if (ncu <= 0) ncu = 256;
+  const int64_t tiles2 = (N / 256) * (K / 256);
+  splits2 = ncu / tiles2;
+  if (splits2 < 1) splits2 = 1;
+  const int64_t max2 = ceil_div(M, 32 * TN_BKM);
+  if (splits2 > max2) splits2 = max2;
+  rows2 = ceil_div(ceil_div(M, splits2), TN_BKM) * TN_BKM;
+  splits2 = ceil_div(M, rows2);
+}
+static bool tn256_ok(int64_t M, int64_t N, int64_t K) { return N % 256 == 0 && K % 256 == 0 && M >= 4096; }
+
+size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K) {
+  if (!meant_opt(MEANT_OPT_DETERMINISTIC)) return 0;
+  M -= M % TN_BKM;
+  if (!tn256_ok(M, N, K)) return 0;
+  int64_t splits2, rows2;
+  tn256_geometry(M, N, K, splits2, rows2);
+  return (size_t)(splits2 * N * K + splits2 * (K / 256) * 4 * N) * sizeof(float);
+}
+
 int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N,
-                        int64_t K, hipStream_t stream) {
+                        int64_t K, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const bool det = meant_opt(MEANT_OPT_DETERMINISTIC) != 0;
   MEANT_REQUIRE((lddy % 8) == 0 && (ldx % 8) == 0 && meant_aligned16(dY) && meant_aligned16(X), MEANT_ERR_ARG,
                 "gemm_bf16_tn: operands must be 16-byte aligned with row strides that are multiples of 8");
   MEANT_REQUIRE(N >= 8 && K >= 8, MEANT_ERR_UNSUPPORTED, "gemm_bf16_tn: N and K must be >= 8");
@@ -1027,26 +1122,31 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
     if (rc || Mmain == 0) return rc;
     M = Mmain;
   }
-  if (N % 256 == 0 && K % 256 == 0 && M >= 4096) {
+  if (tn256_ok(M, N, K)) {
     const int64_t ntn2 = N / 256, ntk2 = K / 256;
-    // one resident block per CU: size the launch to whole rounds of the CU count (a lone block in an extra
-    // round would cost a full round of time) -- one round when every block still gets >= 32 tiles of 64 rows
-    int ncu = meant_num_cus();
-    if (ncu <= 0) ncu = 256;
-    const int64_t tiles2 = ntn2 * ntk2;
-    int64_t splits2 = ncu / tiles2;
-    if (splits2 < 1) splits2 = 1;
-    const int64_t max2 = ceil_div(M, 32 * TN_BKM);
-    if (splits2 > max2) splits2 = max2;
-    int64_t rows2 = ceil_div(ceil_div(M, splits2), TN_BKM) * TN_BKM;
-    splits2 = ceil_div(M, rows2);
-    static bool attr2 = false;
-    if (!attr2) {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN2_TILE);
-      attr2 = true;
+    int64_t splits2, rows2;
+    tn256_geometry(M, N, K, splits2, rows2);
+    const dim3 grid((unsigned)(ntn2 * ntk2 * splits2));
+    if (det) {
+      const size_t need = (size_t)(splits2 * N * K + splits2 * ntk2 * 4 * N) * sizeof(float);
+      MEANT_REQUIRE(ws && ws_bytes >= need && meant_aligned16(ws), MEANT_ERR_WORKSPACE,
+                    "linear_bwd_dw (deterministic): workspace of %zu bytes needed (meant_linear_bwd_dw_ws), got %zu", need, ws_bytes);
+      float* part = (float*)ws;
+      float* pbias = part + splits2 * N * K;
+      MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<true>, 4 * TN2_TILE);
+      meant_route_hit(ROUTE_TN256_DET);
+      hipLaunchKernelGGL(gemm_bf16_tn256_kernel<true>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                         (int)ntk2, rows2, part, pbias);
+      MEANT_LAUNCH_CHECK("gemm_bf16_tn256<det>");
+      hipLaunchKernelGGL(tn256_reduce_kernel, dim3((unsigned)ceil_div(N * K / 4, 256)), dim3(256), 0, stream, part, dbias ? pbias : nullptr, dW, dbias,
+                         N, K, (int)ntk2, (int)(ntn2 * ntk2), (int)splits2);
+      MEANT_LAUNCH_CHECK("tn256_reduce");
+      return MEANT_OK;
     }
-    hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3((unsigned)(ntn2 * ntk2 * splits2)), dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx,
-                       dW, dbias, M, N, K, (int)ntn2, (int)ntk2, rows2);
+    MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<false>, 4 * TN2_TILE);
+    meant_route_hit(ROUTE_TN256);
+    hipLaunchKernelGGL(gemm_bf16_tn256_kernel<false>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                       (int)ntk2, rows2, (float*)nullptr, (float*)nullptr);
     MEANT_LAUNCH_CHECK("gemm_bf16_tn256");
     return MEANT_OK;
   }
@@ -1055,14 +1155,11 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
   int64_t splits = ceil_div(1024, ntn * ntk);
   const int64_t max_splits = ceil_div(M, 256);
   if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  if (splits < 1 || det) splits = 1;                 // deterministic: every output element has exactly one writer
   int64_t rows_per = ceil_div(ceil_div(M, splits), TN_BKM) * TN_BKM;
   splits = ceil_div(M, rows_per);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN_TILE_BYTES);
-    attr_set = true;
-  }
+  MEANT_RAISE_LDS(gemm_bf16_tn_kernel, 4 * TN_TILE_BYTES);
+  meant_route_hit(ROUTE_TN128);
   hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((unsigned)(ntn * ntk * splits)), dim3(256), 4 * TN_TILE_BYTES, stream, dY, lddy, X,
                      ldx, dW, M, N, K, (int)ntn, (int)ntk, rows_per);
   MEANT_LAUNCH_CHECK("gemm_bf16_tn");

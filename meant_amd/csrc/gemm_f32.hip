@@ -120,6 +120,7 @@ int gemm_f32_launch(const GemmF32Args& a, hipStream_t stream) {
   else if (a.in_dtype == MEANT_BF16 && a.out_dtype == MEANT_F32) kern = gemm_f32_kernel<bf16, float>;
   MEANT_REQUIRE(kern, MEANT_ERR_UNSUPPORTED, "gemm_f32: unsupported dtype combination");
   const size_t esz_in = a.in_dtype == MEANT_F32 ? 4 : 2, esz_out = a.out_dtype == MEANT_F32 ? 4 : 2;
+  meant_route_hit(ROUTE_GEMM_F32);
   if (gy <= 65535) {
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.N, BN), (unsigned)gy, (unsigned)gz), dim3(256), 0, stream, a);
   } else {
@@ -146,6 +147,7 @@ int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, 
   }
   int64_t strips = ceil_div(M, 64);
   if (strips > 512) strips = 512;
+  if (meant_opt(MEANT_OPT_DETERMINISTIC)) strips = 1;   // one add per column: nothing races (slow for tall inputs; a debugging mode)
   DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)ceil_div(N, 64), (unsigned)strips), dim3(256), 0, stream, (const T*)x, ldx, out, M, N));
   MEANT_LAUNCH_CHECK("colsum");
   return MEANT_OK;

@@ -74,11 +74,18 @@ __global__ void ce_probs_kernel(const float* __restrict__ x, const int64_t* __re
     for (int c = 0; c < C; ++c) s += expf(r[c] - mx);
     const float lse = mx + logf(s);
     const int64_t t = target[b];
-    l = (lse - r[t]) / (float)B;
-    if (dx) for (int c = 0; c < C; ++c) dx[b * C + c] = (expf(r[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
+    if (t < 0 || t >= C) {
+      // a class index outside [0, C) (torch raises here; a kernel cannot): poison the loss and this row's gradient so that the
+      // caller sees NaN instead of an out-of-bounds read and a silently wrong step
+      l = NAN;
+      if (dx) for (int c = 0; c < C; ++c) dx[b * C + c] = NAN;
+    } else {
+      l = (lse - r[t]) / (float)B;
+      if (dx) for (int c = 0; c < C; ++c) dx[b * C + c] = (expf(r[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
+    }
   }
   l = wave_sum(l);
-  if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+  if ((threadIdx.x & 63) == 0 && !(l == 0.f)) atomicAdd(loss, l);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -179,7 +186,8 @@ extern "C" int meant_adamw_f32(float* p, const float* g, float* m, float* v, int
   MEANT_REQUIRE(p && g && m && v && n >= 0 && step >= 1, MEANT_ERR_ARG, "adamw_f32: bad argument");
   MEANT_REQUIRE(meant_aligned16(p) && meant_aligned16(g) && meant_aligned16(m) && meant_aligned16(v), MEANT_ERR_ARG, "adamw_f32: 16-byte alignment");
   if (n == 0) return MEANT_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  // bias corrections in double (1 - 0.999^t loses ~6e-5 relative in float at small t)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   int64_t nb = ceil_div(n, 256 * 4);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 import weakref
 from typing import Optional
 
@@ -28,10 +29,22 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _need_gpu(*ts):
+    """every tensor must live on the CURRENT HIP device: the library acts on the calling thread's current device (its
+    streams, its per-device kernel state), so a tensor of another GPU would be a cross-device access.  Callers that
+    drive several GPUs from one process (nn.DataParallel replicas) already run each replica under its own
+    torch.cuda.device(...)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("meant_amd: this op runs only on an MI355X (HIP) device; got a tensor on "
                                f"{t.device}.  There is no CPU fallback.")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"meant_amd: tensor on {t.device} but the current device is cuda:{cur}; wrap the call in "
+                               "`with torch.cuda.device(tensor.device):`")
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -50,44 +63,78 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # weight cache: compute-dtype copy and transposed copy of an fp32 parameter, refreshed when the
 # parameter is updated in place (optimizer step bumps ._version) or replaced.
 class _WeightCache:
+    """Entries are keyed on the PARAMETER OBJECTS behind the tensors handed in (a view such as conv.weight.view(N, K) is
+    keyed on its base parameter + geometry), carry weak references to them and are dropped by a finalizer when a parameter
+    dies.  Tensors without a stable identity (results of F.pad / cat / arithmetic) are converted without being cached, so
+    nothing can accumulate from per-step temporaries.  `pad_rows` appends zero rows to the (concatenated) weight before
+    the conversion: the padded bf16 / transposed copies of a vocabulary matrix are built once per optimizer step instead
+    of once per call.  Thread-safe (autograd worker threads, nn.DataParallel replicas)."""
+
     def __init__(self):
         self._store = {}
         self._epoch = 0
+        self._lock = threading.RLock()
 
     def invalidate(self):
         """call after parameters were modified through raw device pointers (the fused optimizer), which does not
         bump their autograd version counters"""
         self._epoch += 1
 
-    def get(self, params, dtype: torch.dtype, transposed: bool):
-        """params: tuple of [N_i, K] fp32 parameters, concatenated along N."""
-        key = (tuple(id(p) for p in params), dtype, transposed)
-        ver = (self._epoch,) + tuple((p._version, p.data_ptr()) for p in params)
-        hit = self._store.get(key)
-        # id() values are recycled once a parameter is freed: an entry is valid only for the very same objects
-        if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
-            return hit[1]
+    @staticmethod
+    def _root(p):
+        base = p._base if p._base is not None else p
+        return base if (base.is_leaf and not isinstance(base, torch.nn.parameter.UninitializedParameter)) else None
+
+    def _drop(self, key):
+        with self._lock:
+            self._store.pop(key, None)
+
+    def _build(self, params, dtype, transposed, pad_rows):
         with torch.no_grad():
             w = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], dim=0)
-            w = _c(w)
+            if pad_rows:
+                w = torch.nn.functional.pad(w, (0, 0, 0, pad_rows))
+            w = _c(w.float())
             N, K = w.shape
-            sd = F32
             dd = F32 if dtype == torch.float32 else BF16
             if transposed:
                 out = torch.empty((K, N), device=w.device, dtype=dtype)
-                check(lib.meant_transpose2d(_p(w), sd, _p(out), dd, N, K, _stream()), "transpose2d")
+                check(lib.meant_transpose2d(_p(w), F32, _p(out), dd, N, K, _stream()), "transpose2d")
             elif dtype == torch.float32:
                 out = w
             else:
                 out = torch.empty((N, K), device=w.device, dtype=dtype)
-                check(lib.meant_cast(_p(w), sd, _p(out), dd, N * K, _stream()), "cast")
-        if len(self._store) > 4096:                    # entries of parameters that no longer exist
-            self._store = {k: v for k, v in self._store.items() if all(r() is not None for r in v[2])}
-        self._store[key] = (ver, out, tuple(weakref.ref(p) for p in params))
+                check(lib.meant_cast(_p(w), F32, _p(out), dd, N * K, _stream()), "cast")
         return out
 
+    def get(self, params, dtype: torch.dtype, transposed: bool, pad_rows: int = 0):
+        """params: tuple of [N_i, K] fp32 tensors, concatenated along N (+ pad_rows zero rows)."""
+        roots = tuple(self._root(p) for p in params)
+        if any(r is None for r in roots):
+            return self._build(params, dtype, transposed, pad_rows)
+        key = (tuple((id(r), tuple(p.shape), p.storage_offset(), p.stride()) for r, p in zip(roots, params)), dtype, transposed,
+               pad_rows, params[0].device)
+        ver = (self._epoch,) + tuple((r._version, r.data_ptr()) for r in roots)
+        with self._lock:
+            hit = self._store.get(key)
+            # id() values are recycled once a parameter is freed: an entry is valid only for the very same objects
+            if hit is not None and hit[0] == ver and all(wr() is r for wr, r in zip(hit[2], roots)):
+                return hit[1]
+        out = self._build(params, dtype, transposed, pad_rows)
+        with self._lock:
+            fresh = key not in self._store
+            self._store[key] = (ver, out, tuple(weakref.ref(r) for r in roots))
+            if fresh:
+                for r in roots:
+                    weakref.finalize(r, self._drop, key)
+        return out
+
+    def __len__(self):
+        return len(self._store)
+
     def clear(self):
-        self._store.clear()
+        with self._lock:
+            self._store.clear()
 
 
 weights = _WeightCache()
@@ -269,19 +316,29 @@ def _linear_fwd_raw(x2, w_c, bias_f, residual2, epilogue, want_preact):
     return y, pre
 
 
-def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias):
-    """returns dx2 (or None), dW [sum N_i, K] fp32, db [sum N_i] fp32 or None"""
+def _bwd_dw(dy2, x2, dw, db):
+    """dw [N, K] += dy2^T x2, db [N] += colsum(dy2) (float accumulators)"""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dt = _dt(dy2)
+    wsb = lib.meant_linear_bwd_dw_ws(M, N, K, dt)          # non-zero only with the "deterministic" option
+    ws = torch.empty(wsb, device=dy2.device, dtype=torch.uint8) if wsb else None
+    check(lib.meant_linear_bwd_dw(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(dw), _p(db), M, N, K, dt, _p(ws), wsb, _stream()),
+          "linear_bwd_dw")
+
+
+def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0):
+    """returns dx2 (or None), dW [sum N_i (+ pad_rows), K] fp32, db [same] fp32 or None"""
     M, N = dy2.shape
     K = x2.shape[1]
     dx = None
     if need_dx:
-        wT = weights.get(params, dy2.dtype, True)             # [K, N]
+        wT = weights.get(params, dy2.dtype, True, pad_rows)             # [K, N]
         dx = torch.empty((M, K), device=dy2.device, dtype=dy2.dtype)
         check(lib.meant_linear_bwd_dx(_p(dy2), dy2.stride(0), _p(wT), _p(dx), K, M, N, K, _dt(dy2), _stream()), "linear_bwd_dx")
     dw = torch.zeros((N, K), device=dy2.device, dtype=torch.float32)
     db = torch.zeros(N, device=dy2.device, dtype=torch.float32) if has_bias else None
-    check(lib.meant_linear_bwd_dw(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(dw), _p(db), M, N, K, _dt(dy2), _stream()),
-          "linear_bwd_dw")
+    _bwd_dw(dy2, x2, dw, db)
     return dx, dw, db
 
 
@@ -439,7 +496,7 @@ class _QKVAttention(torch.autograd.Function):
             check(lib.meant_linear_bwd_dx(_p(dqkv), N, _p(wT), _p(dx), K, M, N, K, dt, _stream()), "linear_bwd_dx")
         dw = torch.zeros((N, K), device=do2.device, dtype=torch.float32)
         db = torch.zeros(N, device=do2.device, dtype=torch.float32)
-        check(lib.meant_linear_bwd_dw(_p(dqkv), N, _p(x2), x2.stride(0), _p(dw), _p(db), M, N, K, dt, _stream()), "linear_bwd_dw")
+        _bwd_dw(dqkv, x2, dw, db)
         return (dx.view(G, S, d) if dx is not None else None), dw, db, None, None, None, None, None
 
 
@@ -711,21 +768,46 @@ class _SoftmaxCE(torch.autograd.Function):
         return dl, None, None, None
 
 
+class _VocabLinear(torch.autograd.Function):
+    """x W^T + b on W [V, d] with the output rows padded to Vp = ceil(V / 256) * 256 columns.  The padded bf16 copy of W
+    (forward) and its transpose (input gradient) come from the weight cache keyed on the real parameter, so they are
+    rebuilt once per optimizer step, not per call; the gradient is produced for the Vp rows and the V real ones handed
+    back as a view (no pad / un-pad passes over the 196 MB matrix)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight)
+        V, d = weight.shape
+        Vp = (V + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD
+        shp = x.shape
+        x2 = _c(x).view(-1, d)
+        w_c = weights.get((weight,), x.dtype, False, Vp - V)
+        bias_f = None
+        if bias is not None:
+            bias_f = _c(torch.nn.functional.pad(bias.detach().float(), (0, Vp - V)))
+        y, _ = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_NONE, False)
+        ctx.weight, ctx.has_bias, ctx.in_shape, ctx.V = weight, bias is not None, shp, V
+        ctx.save_for_backward(x2)
+        return y.view(*shp[:-1], Vp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        V = ctx.V
+        Vp = dy.shape[-1]
+        dy2 = _c(dy).view(-1, Vp)
+        dx, dw, db = _linear_bwd_raw(dy2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias, pad_rows=Vp - V)
+        return (dx.view(ctx.in_shape) if dx is not None else None), dw[:V], (db[:V] if db is not None else None)
+
+
 def _vocab_logits_padded(x, weight, bias):
-    V, d = weight.shape
-    Vp = (V + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD
-    wp = torch.nn.functional.pad(weight, (0, 0, 0, Vp - V)) if Vp != V else weight
-    bp = None
-    if bias is not None:
-        bp = torch.nn.functional.pad(bias, (0, Vp - V)) if Vp != V else bias
-    return linear(x, wp, bp)                           # [..., Vp]
+    return _VocabLinear.apply(x, weight, bias)                           # [..., Vp]
 
 
 def vocab_linear(x, weight, bias=None):
     """logits = x W^T + b for a big (tied) vocabulary matrix W [V, d] (pretrain_mlm.py:88 -> RobertaLMHead.decoder).
     Returns a [..., V] VIEW of a buffer whose rows are padded to a multiple of 256 columns, so that the GEMM takes
-    the streaming 256 x 256 kernel.  The padding rows of W are zeros appended by a differentiable op: gradients come
-    back for exactly the V real rows."""
+    the streaming 256 x 256 kernel (padding rows of W are zeros; gradients come back for exactly the V real rows)."""
     return _vocab_logits_padded(x, weight, bias)[..., :weight.shape[0]]
 
 

@@ -28,6 +28,20 @@ def test_ce_on_probs_matches_torch(dev):
         assert (ph.grad.cpu() - pr.grad).abs().max().item() < 1e-6
 
 
+def test_ce_on_probs_out_of_range_target_is_flagged(dev):
+    """torch raises for a class index outside [0, C); the kernel poisons the loss and that row's gradient with NaN instead of
+    reading out of bounds (in_loop_train.py:232 feeds 2-class heads; a 3-class label is the typical mistake)"""
+    from meant_amd.train import cross_entropy_on_probs
+    probs = torch.rand(6, 2, device=dev, requires_grad=True)
+    for bad in (2, -100, 10 ** 9):
+        tgt = torch.tensor([0, 1, bad, 1, 0, 1], device=dev)
+        out = cross_entropy_on_probs(probs, tgt)
+        assert torch.isnan(out)
+        probs.grad = None
+        out.backward()
+        assert torch.isnan(probs.grad[2]).all() and torch.isfinite(probs.grad[[0, 1, 3, 4, 5]]).all()
+
+
 @pytest.mark.parametrize("max_norm", [None, 1.0, 1e-3])
 def test_fused_adamw_matches_torch(dev, max_norm):
     """3 steps of clip_grad_norm_ + torch.optim.AdamW on the CPU vs the fused flat-bucket kernels"""

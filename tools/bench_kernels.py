@@ -46,7 +46,7 @@ def bench_gemm():
         x = torch.randn(M, K, device=dev).bfloat16()
         dw = torch.zeros(N, K, device=dev)
         db = torch.zeros(N, device=dev)
-        f = lambda: check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, N, K, BF16, st()))
+        f = lambda: check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, N, K, BF16, None, 0, st()))
         t = timeit(f)
         print(f"  M={M:7d} N={N:5d} K={K:5d}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TFLOP/s")
         dw.zero_(); db.zero_(); f(); torch.cuda.synchronize()

@@ -12,7 +12,7 @@ for (N, K) in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
     db = torch.zeros(N, device=dev)
     # meant_linear_bwd_dw(dy, lddy, x, ldx, dw, dbias, M, N, K, dtype, stream)
     def run():
-        check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr() if os.environ.get("NOBIAS") is None else None, M, N, K, 1, st), "dw")
+        check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr() if os.environ.get("NOBIAS") is None else None, M, N, K, 1, None, 0, st), "dw")
     run(); torch.cuda.synchronize()
     ref = dy[:, :64].float().t() @ x[:, :64].float()
     err = (dw[:64, :64] - ref).abs().max().item() / ref.abs().max().item()

@@ -15,7 +15,7 @@ for (N, K) in [(768, 768), (2304, 768), (768, 3072)]:
         dw = torch.zeros(N, K, device=dev)
         db = torch.zeros(N, device=dev)
         def run():
-            check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, N, K, 1, st), "dw")
+            check(lib.meant_linear_bwd_dw(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, N, K, 1, None, 0, st), "dw")
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
