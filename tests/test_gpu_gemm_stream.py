@@ -157,11 +157,11 @@ def test_streaming_qkv_projection_with_rotary(L, dev, G, S, H, Dh, R, dynamic, c
 @pytest.mark.parametrize("dynamic", [1, 0], ids=["dyn", "fixed"])
 def test_vocab_gemm_cross_entropy_at_streaming_scale(L, dev, dynamic):
     """pretrain_mlm.py:88,160: logits = h W^T + b over V = 64001 (padded to 64256 = 251 column tiles), mean CE with
-    ignore_index -100, at T = 8192 tokens: 32 x 251 = 8032 tiles through the streaming kernel forward, its dX
+    ignore_index -100, at T = 11264 tokens: 44 x 251 = 11044 tiles through the streaming kernel forward, its dX
     (K = 64256: 1004 K-steps per tile) and the 256 x 256 dW kernel, against F.cross_entropy in fp32 on the CPU."""
     from meant_amd import ops
     L.set_option("nt_dynamic", dynamic)
-    T, V, d = 8192, 64001, 768
+    T, V, d = 11264, 64001, 768
     rs = np.random.RandomState(7)
     x, w, b = _rand(rs, T, d), _rand(rs, V, d, scale=1 / math.sqrt(d)), _rand(rs, V, scale=0.1)
     tgt = torch.from_numpy(rs.randint(0, V, size=T))
