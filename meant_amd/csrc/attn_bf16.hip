@@ -39,6 +39,11 @@ constexpr int TILE_B = KV_TILE * DH * 2;          // 8 KiB
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PADL2 = 1e9f * 1.4426950408889634f;  // the reference's (1-mask) * -1e9 key-padding term, in log2 units
 
+// tell the compiler a condition is wave-uniform (it cannot prove it for values that came through vector loads or
+// ballots): a branch on a "divergent" bool is compiled to exec masking, and every accumulator live across it gets
+// copied at the join (the dK/dV loop carried 128 v_mov_b64 per tile for that reason)
+__device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+
 __device__ __forceinline__ int swz(int r) { return ((r & 2) << 1) | ((r >> 2) & 3); }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -639,6 +644,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 struct BwdArgs {
   const bf16* qkv; const bf16* o; const bf16* dout; const float* lse; const float* bias2; const int* flags; bf16* dqkv; float* delta;
   const uint64_t* masks;                             // packed tile masks per group (null when S > 4096)
+  int64_t plane;                                     // G*H*S: `delta` holds two planes, -(m + log2 l) and -delta, per (g, h, query)
   int S, H; float scale; int causal;
   RotTables rot;                                     // adjoint rotary on dq / dk when rot.qa != null
 };
@@ -700,8 +706,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     m_q = lp[0];
     logl_q = lp[1];
   }
-  if (lane < 32 && myq < S) a.delta[((int64_t)g * H + h) * S + myq] = delta;
   const float nml = -(m_q + logl_q);                 // used on tiles without padding, where |m| is small and the sum is exact enough
+  // per-query planes for the dK/dV pass: -(m + log2 l) and -delta (it starts its dP accumulators from the latter)
+  if (lane < 32 && myq < S) {
+    a.delta[((int64_t)g * H + h) * S + myq] = nml;
+    a.delta[a.plane + ((int64_t)g * H + h) * S + myq] = -delta;
+  }
 
   int kend = S;
   if (a.causal) { const int lastq = qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
@@ -803,14 +813,63 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // backward, pass 2: dK, dV.  workgroup = 4 waves x 32 keys; Q / dO tiles of 64 queries stream through LDS.
+//
+// Per 32-query x 32-key block a lane holds 16 scores (its key, 16 query rows).  Two code paths, chosen per block by
+// wave-uniform conditions, so that the common one is branch-free and as short as the arithmetic allows:
+//   plain   -- every key of the wave is live (bias 0) and the block touches neither the diagonal nor the end of the
+//              sequence: p = exp2(s * c1 + nml[q]) with nml = -(m + log2 l) precomputed per query by the dQ pass (exact
+//              enough here: a query that sees a live key has a small m), dS = p * dP' with the dP accumulator STARTED at
+//              -delta[q] (loaded from LDS straight into the accumulator registers), i.e. fma, exp, mul per score;
+//   careful -- padding keys, the causal diagonal or the ragged last query tile: the reference's arithmetic step by step,
+//              exp2((s * c1 + bias - m) - log2 l) (m ~ -1e9 on fully padded rows, where m + log2 l is not representable),
+//              masked by selects.
+// The previous form evaluated the careful path's conditions per element behind divergent branches: 1209 instructions per
+// 64-query tile and wave for 32 MFMAs (485 of them scalar mask bookkeeping); this one issues ~330.
+// ------------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV.  workgroup = 4 waves x 32 keys; Q / dO tiles of 64 queries stream through LDS.
+//
+// Per 32-query x 32-key block a lane holds 16 scores (its key, 16 query rows).  The body of the kernel exists in two
+// variants and each workgroup (128 keys of one (g, h)) runs exactly one of them from its first load to its last store:
+//   PLAIN   -- all 128 keys are live (bias 0): p = exp2(s * c1 + nml[q]) with nml = -(m + log2 l) precomputed per query by
+//              the dQ pass (exact enough here: a query that sees a live key has a small m), dS = p * dP' with the dP
+//              accumulator STARTED at -delta[q] (loaded from LDS straight into the accumulator registers), i.e. fma, exp,
+//              mul per score.  A quarter..half of the text blocks, all of the vision ones.
+//   careful -- some key is padding or lies past the end of the sequence: the reference's arithmetic step by step,
+//              exp2((s * c1 + bias - m) - log2 l) (m ~ -1e9 on fully padded rows, where m + log2 l is not representable).
+//              Blocks made of dead key tiles only (flags bit 1) write their zeros here and leave.
+// Why two whole bodies and not a branch inside the loop: a 64-query tile is ONE basic block -- scores of both 32-query blocks, weights of block
+// 0, products of block 0, weights of block 1, products of block 1 -- so that hipcc's scheduler can put one block's softmax
+// arithmetic between the other block's MFMAs (an MFMA occupies the wave's issue port for 8 of its 32 cycles; ~5 vector
+// instructions fit in each gap).  Every wave-uniform branch inside would end the basic block, and a branch around an MFMA
+// costs copies of the accumulators it touches.  The only branch left goes around the selects that zero the weights of
+// invisible / non-existent queries on the causal diagonal and in a ragged last query tile (a block entirely above the
+// diagonal is masked to zero, not skipped).
+// History: the first form evaluated every mask condition per element behind divergent branches: 1209 instructions per
+// tile and wave for 32 MFMAs (485 of them scalar mask bookkeeping); this one issues ~330.
+#ifdef ATTN_LAB_STAMP
+// lab build only (tools/lab): per-workgroup cycle stamps of the dK/dV kernel
+constexpr int64_t LAB_MAX_WG = 80000;
+__device__ unsigned long long g_lab_stamp[LAB_MAX_WG * 4];
+__device__ __forceinline__ unsigned long long lab_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
 template <int NH>
 __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // two buffers of [Q: NH sub-tiles | dO: NH sub-tiles], stats[2][3][64] floats, 4 patches (NH = 2: in the tile space)
+#ifdef ATTN_LAB_STAMP
+  const unsigned long long lab_t0 = lab_now();
+  unsigned long long lab_t1 = 0, lab_t2 = 0;
+#endif
+  // two buffers of [Q: NH sub-tiles | dO: NH sub-tiles], stats[2][4][64] floats, 4 patches (NH = 2: in the tile space)
   constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;
   float* stats = reinterpret_cast<float*>(smem + 2 * BUF_B);
-  char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 3 * 64 * 4 : smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 4 * 64 * 4 : smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
   const int g = blockIdx.z, h = blockIdx.y;
@@ -821,8 +880,42 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
   const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
   const bf16* dO = a.dout + (int64_t)g * S * D + h * HD;
   const float* lse = a.lse + ((int64_t)g * H + h) * S * 2;
-  const float* dl = a.delta + ((int64_t)g * H + h) * S;
+  const float* nmlp = a.delta + ((int64_t)g * H + h) * S;
+  const float* ndp = nmlp + a.plane;
 
+  // which kernel serves this block: flags bit 0 of a 64-key tile = some key of it carries a bias (padding, or past S);
+  // bit 1 = the whole tile is dead padding (exactly zero dK / dV)
+  const int ntile = (S + KV_TILE - 1) / KV_TILE;
+  const int* flg = a.flags + (int64_t)g * ntile;
+  const int kt_lo = kb0 / KV_TILE, kt_hi = (kb0 + 64 < S) ? kt_lo + 1 : kt_lo;
+  bool wave_dead, block_dead, block_plain;
+  if (a.masks) {                                       // scalar load: everything below depends on it
+    uint64_t sp, sk;
+    sload_masks(a.masks + 2 * (int64_t)g, sp, sk);
+    wave_dead = key0 < S && ((sk >> (key0 / KV_TILE)) & 1);
+    block_dead = ((sk >> kt_lo) & 1) && ((sk >> kt_hi) & 1);
+    block_plain = !((sp >> kt_lo) & 1) && !((sp >> kt_hi) & 1);
+  } else {
+    wave_dead = key0 < S && (flg[key0 / KV_TILE] & 2);
+    block_dead = (flg[kt_lo] & 2) && (flg[kt_hi] & 2);
+    block_plain = !(flg[kt_lo] & 1) && !(flg[kt_hi] & 1);
+  }
+  wave_dead = uni(wave_dead);
+  block_dead = uni(block_dead);
+  block_plain = uni(block_plain && kb0 + 128 <= S);
+  if (block_dead) {
+    bf16* dkp = a.dqkv + (int64_t)g * S * ld + D + h * HD;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int idx = tid; idx < 128 * 2 * (HD / 8); idx += 256) {      // 128 keys x (dK | dV) x HD/8 16-byte chunks
+      const int row = idx / (2 * (HD / 8)), c = idx % (2 * (HD / 8));
+      if (kb0 + row < S) *reinterpret_cast<u32x4*>(dkp + (int64_t)(kb0 + row) * ld + (c / (HD / 8)) * D + (c % (HD / 8)) * 8) = z;
+    }
+    return;
+  }
+
+  // the rest of the kernel exists twice, once per variant: the two never join again, so no accumulator is copied
+  auto body = [&](auto PLAIN_T) {
+  constexpr bool PLAIN = decltype(PLAIN_T)::value;
   bf16x8 kf[4 * NH], vf[4 * NH];
   {
     const bf16* kp = base + (int64_t)krow * ld + D + 8 * (lane >> 5);
@@ -834,8 +927,8 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
     }
   }
   const float c1 = a.scale * LOG2E;
-  const int ntile = (S + KV_TILE - 1) / KV_TILE;
-  const float bkey = mykey < ntile * KV_TILE ? a.bias2[(int64_t)g * ntile * KV_TILE + mykey] : -INFINITY;   // key bias (log2 units; -inf past S)
+  float bkey = 0.f;                                    // key bias (log2 units; -inf past S); zero by construction when PLAIN
+  if (!PLAIN) bkey = mykey < ntile * KV_TILE ? a.bias2[(int64_t)g * ntile * KV_TILE + mykey] : -INFINITY;
 
   f32x16 dkacc[2 * NH], dvacc[2 * NH];
 #pragma unroll
@@ -843,24 +936,11 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dkacc[b][e] = 0.f; dvacc[b][e] = 0.f; }
 
-  // keys of an all-padding tile get exactly zero dK / dV (flags bit 1): their waves sit the loop out, and a block
-  // made of such tiles only writes its zeros
-  const int* flg = a.flags + (int64_t)g * ntile;
-  const int kt_lo = kb0 / KV_TILE, kt_hi = (kb0 + 64 < S) ? kt_lo + 1 : kt_lo;
-  bool wave_dead, block_dead;
-  if (a.masks) {                                       // scalar load: the first DMA below depends on it
-    uint64_t sp, sk;
-    sload_masks(a.masks + 2 * (int64_t)g, sp, sk);
-    wave_dead = key0 < S && ((sk >> (key0 / KV_TILE)) & 1);
-    block_dead = ((sk >> kt_lo) & 1) && ((sk >> kt_hi) & 1);
-  } else {
-    wave_dead = key0 < S && (flg[key0 / KV_TILE] & 2);
-    block_dead = (flg[kt_lo] & 2) && (flg[kt_hi] & 2);
-  }
   const int nt = (S + 63) / 64;
-  const int t0 = block_dead ? nt : (a.causal ? kb0 / 64 : 0);   // first query tile that can see this block's keys
+  const int t0 = a.causal ? kb0 / 64 : 0;              // first query tile that can see this block's keys
 
-  // per-tile statistics by DMA too: st[0..127] = interleaved (m, log l) pairs of the 64 queries, st[128..191] = delta
+  // per-tile statistics by DMA too: st[0..127] = interleaved (m, log2 l) pairs of the 64 queries (careful kernel),
+  // st[128..191] = -(m + log2 l) (plain kernel), st[192..255] = -delta
   const StageOff soff_q = make_stage_off(ld, S, wave, lane), soff_do = make_stage_off(D, S, wave, lane);
   auto stage = [&](int t, int buf) {
 #pragma unroll
@@ -869,128 +949,219 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
       stage64(dO + DH * hf, D, t * 64, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff_do);
     }
     if (wave == 0) {
-      float* st = stats + buf * 192;
-      const int last = 2 * S - 1;
-      int i0 = t * 128 + lane, i1 = t * 128 + 64 + lane, qd = t * 64 + lane;
-      i0 = i0 < last ? i0 : last;
-      i1 = i1 < last ? i1 : last;
+      float* st = stats + buf * 256;
+      int qd = t * 64 + lane;
       qd = qd < S ? qd : S - 1;
-      glds4(lse + i0, st);
-      glds4(lse + i1, st + 64);
-      glds4(dl + qd, st + 128);
+      if (PLAIN) {
+        glds4(nmlp + qd, st + 128);
+      } else {
+        const int last = 2 * S - 1;
+        int i0 = t * 128 + lane, i1 = t * 128 + 64 + lane;
+        i0 = i0 < last ? i0 : last;
+        i1 = i1 < last ? i1 : last;
+        glds4(lse + i0, st);
+        glds4(lse + i1, st + 64);
+      }
+      glds4(ndp + qd, st + 192);
     }
   };
   const TrOff troff = make_troff(lane);
+  // row-fragment offsets inside a tile for the four k-steps (the XOR swizzle makes them lane-dependent; the 32-row block
+  // and the tile are added as uniform terms)
+  unsigned foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = (unsigned)((lane & 31) * 128 + (((2 * ks + (lane >> 5)) ^ swz(lane & 31)) << 4));
+  const bool wave_live = uni(key0 < S && !wave_dead);
 
+  // one 64-query tile of this wave's 32 keys
+  auto tile = [&](int qt0, int buf) {
+    const float* st = stats + buf * 256;
+    const char* Qb = smem + buf * BUF_B;
+    const char* dOb = Qb + NH * TILE_B;
+    const int qrow0 = 4 * (lane >> 5);                           // + 32 sq + 8 g4 + e4: local query row of element e
+    f32x16 sacc[2], dpacc[2];
+    auto scores = [&](auto SQ) {
+      constexpr int sq = decltype(SQ)::value;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[sq][e] = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(st + 192 + 32 * sq + qrow0 + 8 * g4);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) dpacc[sq][g4 * 4 + e4] = nd[e4];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4 * NH; ++ks) {
+        const bf16x8 qv = *reinterpret_cast<const bf16x8*>(Qb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dOb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
+        sacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qv, kf[ks], sacc[sq], 0, 0, 0);
+        dpacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv, vf[ks], dpacc[sq], 0, 0, 0);
+      }
+    };
+    auto weights = [&](auto SQ, bf16x8 (&pf)[2], bf16x8 (&dsf)[2]) {
+      constexpr int sq = decltype(SQ)::value;
+      if (PLAIN) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 nm = *reinterpret_cast<const f32x4*>(st + 128 + 32 * sq + qrow0 + 8 * g4);
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) sacc[sq][g4 * 4 + e4] = __builtin_amdgcn_exp2f(fmaf(sacc[sq][g4 * 4 + e4], c1, nm[e4]));
+        }
+      } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 ml0 = *reinterpret_cast<const f32x4*>(st + 2 * (32 * sq + qrow0 + 8 * g4));       // m0 l0 m1 l1
+          const f32x4 ml1 = *reinterpret_cast<const f32x4*>(st + 2 * (32 * sq + qrow0 + 8 * g4) + 4);   // m2 l2 m3 l3
+          const float mv[4] = {ml0[0], ml0[2], ml1[0], ml1[2]};
+          const float lv[4] = {ml0[1], ml0[3], ml1[1], ml1[3]};
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const float tv = fmaf(sacc[sq][g4 * 4 + e4], c1, bkey);
+            sacc[sq][g4 * 4 + e4] = __builtin_amdgcn_exp2f((tv - mv[e4]) - lv[e4]);
+          }
+        }
+      }
+      // the block touches (or lies above) this wave's stretch of the causal diagonal, or runs past the last query: zero the
+      // weights of invisible / non-existent queries.  (A branch around vector instructions only: no accumulator is live
+      // across it that an MFMA writes.)
+      if (uni(((a.causal != 0) & (qt0 + 32 * sq < key0 + 31)) | (qt0 + 32 * sq + 32 > S))) {   // '&', '|': no short-circuit branches
+        const int qvis = a.causal ? mykey : -1;          // a query q sees this lane's key iff q >= qvis (and q < S)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int q = qt0 + 32 * sq + qrow0 + 8 * (e >> 2) + (e & 3);
+          sacc[sq][e] = (q < qvis || q >= S) ? 0.f : sacc[sq][e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dpacc[sq][e] *= sacc[sq][e];    // dS / scale  (dP was started at -delta)
+      acc_to_frags(sacc[sq], pf[0], pf[1]);
+      acc_to_frags(dpacc[sq], dsf[0], dsf[1]);
+    };
+    auto products = [&](auto SQ, const bf16x8 (&pf)[2], const bf16x8 (&dsf)[2]) {
+      constexpr int sq = decltype(SQ)::value;
+      const unsigned qaddr = lds_addr(Qb) + sq * 4096, doaddr = lds_addr(dOb) + sq * 4096;
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf) {
+        u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
+        tr_issue<0>(doaddr + hf * TILE_B, troff, 0, dlo[0][0], dhi[0][0]);
+        tr_issue<0>(doaddr + hf * TILE_B, troff, 1, dlo[0][1], dhi[0][1]);
+        tr_issue<16>(doaddr + hf * TILE_B, troff, 0, dlo[1][0], dhi[1][0]);
+        tr_issue<16>(doaddr + hf * TILE_B, troff, 1, dlo[1][1], dhi[1][1]);
+        tr_issue<0>(qaddr + hf * TILE_B, troff, 0, qlo[0][0], qhi[0][0]);
+        tr_issue<0>(qaddr + hf * TILE_B, troff, 1, qlo[0][1], qhi[0][1]);
+        tr_issue<16>(qaddr + hf * TILE_B, troff, 0, qlo[1][0], qhi[1][0]);
+        tr_issue<16>(qaddr + hf * TILE_B, troff, 1, qlo[1][1], qhi[1][1]);
+        // the wait names the sixteen results as in/out operands: their consumers depend on it, and nothing else does -- no
+        // scheduling fence, so the other block's softmax arithmetic may be placed between the MFMAs that follow
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dlo[0][0]), "+v"(dhi[0][0]), "+v"(dlo[0][1]), "+v"(dhi[0][1]), "+v"(dlo[1][0]), "+v"(dhi[1][0]), "+v"(dlo[1][1]),
+                       "+v"(dhi[1][1]), "+v"(qlo[0][0]), "+v"(qhi[0][0]), "+v"(qlo[0][1]), "+v"(qhi[0][1]), "+v"(qlo[1][0]), "+v"(qhi[1][0]),
+                       "+v"(qlo[1][1]), "+v"(qhi[1][1]));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            dvacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[2 * hf + b], 0, 0, 0);
+            dkacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[2 * hf + b], 0, 0, 0);
+          }
+      }
+    };
+    const std::integral_constant<int, 0> B0{};
+    const std::integral_constant<int, 1> B1{};
+    bf16x8 pf0[2], dsf0[2], pf1[2], dsf1[2];
+    // scheduling fences bound what hipcc may overlap (without them it hoists every LDS read of the tile to the top and spills
+    // a hundred registers): [scores 1 | weights 0] and [products 0 | weights 1] are the two regions where one block's vector
+    // arithmetic is meant to sit between the other block's MFMAs
+    scores(B0);
+    __builtin_amdgcn_sched_barrier(0);
+    scores(B1);
+    weights(B0, pf0, dsf0);
+    __builtin_amdgcn_sched_barrier(0);
+    products(B0, pf0, dsf0);
+    weights(B1, pf1, dsf1);
+    __builtin_amdgcn_sched_barrier(0);
+    products(B1, pf1, dsf1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#ifdef ATTN_LAB_STAMP
+  lab_t1 = lab_now();
+#endif
   if (t0 < nt) {
     stage(t0, 0);
     __syncthreads();
   }
   for (int t = t0; t < nt; ++t) {
     const int buf = (t - t0) & 1;
+#ifndef ATTN_LAB_NODMA
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
+#endif
     const int qt0 = t * 64;
-    const bool active = (key0 < S) && !wave_dead && (!a.causal || (qt0 + 63 >= key0));
-    if (active) {
-      const char* Qt = smem + buf * BUF_B;
-      const char* dOt = Qt + NH * TILE_B;
-      const float* st = stats + buf * 192;
-      const unsigned qaddr = lds_addr(Qt), doaddr = lds_addr(dOt);
-      auto body = [&](auto SQ) {
-        constexpr int sq = decltype(SQ)::value;
-        const int qs0 = qt0 + 32 * sq;
-        if (a.causal && qs0 + 31 < key0) return;     // wave-uniform
-        f32x16 sacc, dpacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 4 * NH; ++ks) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qt + (ks >> 2) * TILE_B, 32 * sq, ks & 3, lane), kf[ks], sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dOt + (ks >> 2) * TILE_B, 32 * sq, ks & 3, lane), vf[ks], dpacc, 0, 0, 0);
-        }
-        const bool diag = a.causal && (qs0 < key0 + 31);
-        const bool tail = qs0 + 32 > S;
-        const bool special = diag || tail;             // wave-uniform
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int ql = 32 * sq + 8 * g4 + 4 * (lane >> 5);          // 4 consecutive local query rows
-          const f32x4 ml0 = *reinterpret_cast<const f32x4*>(st + 2 * ql);       // m0 l0 m1 l1
-          const f32x4 ml1 = *reinterpret_cast<const f32x4*>(st + 2 * ql + 4);   // m2 l2 m3 l3
-          const f32x4 dv = *reinterpret_cast<const f32x4*>(st + 128 + ql);
-          const float mv[4] = {ml0[0], ml0[2], ml1[0], ml1[2]};
-          const float lv[4] = {ml0[1], ml0[3], ml1[1], ml1[3]};
-#pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) {
-            const int e = g4 * 4 + e4;
-            const float t = fmaf(sacc[e], c1, bkey);
-            float p = __builtin_amdgcn_exp2f((t - mv[e4]) - lv[e4]);
-            if (special) {
-              const int q = qt0 + ql + e4;
-              if ((diag && mykey > q) || (tail && q >= S)) p = 0.f;
-            }
-            sacc[e] = p;
-            dpacc[e] = p * (dpacc[e] - dv[e4]);              // dS / scale
-          }
-        }
-        bf16x8 pf[2], dsf[2];
-        acc_to_frags(sacc, pf[0], pf[1]);
-        acc_to_frags(dpacc, dsf[0], dsf[1]);
-#pragma unroll
-        for (int hf = 0; hf < NH; ++hf) {
-          u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
-          tr_issue<32 * sq>(doaddr + hf * TILE_B, troff, 0, dlo[0][0], dhi[0][0]);
-          tr_issue<32 * sq>(doaddr + hf * TILE_B, troff, 1, dlo[0][1], dhi[0][1]);
-          tr_issue<32 * sq + 16>(doaddr + hf * TILE_B, troff, 0, dlo[1][0], dhi[1][0]);
-          tr_issue<32 * sq + 16>(doaddr + hf * TILE_B, troff, 1, dlo[1][1], dhi[1][1]);
-          tr_issue<32 * sq>(qaddr + hf * TILE_B, troff, 0, qlo[0][0], qhi[0][0]);
-          tr_issue<32 * sq>(qaddr + hf * TILE_B, troff, 1, qlo[0][1], qhi[0][1]);
-          tr_issue<32 * sq + 16>(qaddr + hf * TILE_B, troff, 0, qlo[1][0], qhi[1][0]);
-          tr_issue<32 * sq + 16>(qaddr + hf * TILE_B, troff, 1, qlo[1][1], qhi[1][1]);
-          lds_wait_all();
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              dvacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[2 * hf + b], 0, 0, 0);
-              dkacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[2 * hf + b], 0, 0, 0);
-            }
-        }
-      };
-      body(std::integral_constant<int, 0>{});
-      body(std::integral_constant<int, 1>{});
-    }
+    if (wave_live) tile(qt0, buf);
+#ifndef ATTN_LAB_NOBARRIER
     __syncthreads();
+#endif
   }
+#ifdef ATTN_LAB_STAMP
+  lab_t2 = lab_now();
+  auto lab_out = [&]() {
+    if (tid == 0) {
+      const int64_t wg = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      if (wg < LAB_MAX_WG) {
+        unsigned long long* o = g_lab_stamp + wg * 4;
+        o[0] = lab_t1 - lab_t0; o[1] = lab_t2 - lab_t1; o[2] = lab_now() - lab_t2; o[3] = (unsigned long long)(t0 < nt ? nt - t0 : 0);
+      }
+    }
+  };
+  if (key0 >= S) { lab_out(); return; }
+#endif
   if (key0 >= S) return;
-  if (a.rot.ka) rotary_adjoint_regs(reinterpret_cast<f32x16(&)[2]>(dkacc[0]), a.rot.ka, a.rot.kb, a.rot.R, krow, lane);
+  // dV first: it needs no rotary tables, so its LDS round trip and stores go out while dK's table rows are on their way
   char* patch = patches + wave * (32 * 144);
 #pragma unroll
   for (int hf = 0; hf < NH; ++hf) {
     if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    store_transposed(reinterpret_cast<const f32x16(&)[2]>(dkacc[2 * hf]), a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * HD + DH * hf,
-                     ld, key0, S, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(dvacc[2 * hf]), 1.0f, patch, a.dqkv + (int64_t)g * S * ld + 2 * D + h * HD + DH * hf,
                      ld, key0, S, lane);
   }
+  if (a.rot.ka) rotary_adjoint_regs(reinterpret_cast<f32x16(&)[2]>(dkacc[0]), a.rot.ka, a.rot.kb, a.rot.R, krow, lane);
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    store_transposed(reinterpret_cast<const f32x16(&)[2]>(dkacc[2 * hf]), a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * HD + DH * hf,
+                     ld, key0, S, lane);
+  }
+#ifdef ATTN_LAB_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lab_out();
+#endif
+  };
+  if (block_plain) body(std::true_type{});
+  else body(std::false_type{});
 }
 
-constexpr int BWD_DKV_LDS = 4 * TILE_B + 2 * 3 * 64 * 4 + 4 * 32 * 144;
+constexpr int BWD_DKV_LDS = 4 * TILE_B + 2 * 4 * 64 * 4 + 4 * 32 * 144;
 constexpr int FWD_LDS = 4 * TILE_B + 2 * 64 * 4 + 4 * 32 * 144;
 // head dim 128 (NH = 2): twice the tile space, the output patches live in it (2 workgroups per CU by LDS)
-constexpr int BWD_DKV_LDS2 = 8 * TILE_B + 2 * 3 * 64 * 4;
+constexpr int BWD_DKV_LDS2 = 8 * TILE_B + 2 * 4 * 64 * 4;
 constexpr int FWD_LDS2 = 8 * TILE_B + 2 * 64 * 4;
 __host__ inline bool native_dh(int Dh) { return Dh == DH || Dh == 2 * DH; }
 
 }  // namespace
+
+#ifdef ATTN_LAB_STAMP
+extern "C" int meant_lab_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lab_stamp), bytes < sizeof(g_lab_stamp) ? bytes : sizeof(g_lab_stamp));
+}
+#endif
 
 // Head dims 64 and 128 run on the MFMA kernels above (128 as two 64-column halves of every tile).  The host side pads
 // other head dims below 128 up to 128 with zero columns (meant_amd/ops.py: the reference's default 8 heads -> Dh = 96),
 // so this is what they run on too.  Anything else handed to the C ABI directly takes a widening detour: bf16 -> f32
 // copies in the workspace, the fp32 attention core, f32 -> bf16.  Correct for any Dh, not fast.
 // workspace of the Dh=64 path: [delta: G*H*S floats | bias2: G*nt*64 floats | flags: G*nt ints | masks: G * 2 u64]
-static size_t ws_delta_bytes(int64_t G, int64_t S, int H) { return align256((size_t)G * H * S * sizeof(float)); }
+static size_t ws_delta_bytes(int64_t G, int64_t S, int H) { return align256((size_t)G * H * S * 2 * sizeof(float)); }   // two planes
 static size_t ws_bias_bytes(int64_t G, int64_t S) { return align256((size_t)G * ceil_div(S, KV_TILE) * KV_TILE * sizeof(float)); }
 static size_t ws_flag_bytes(int64_t G, int64_t S) { return align256((size_t)G * ceil_div(S, KV_TILE) * sizeof(int)); }
 static size_t ws_mask_bytes(int64_t G) { return align256((size_t)G * 2 * sizeof(uint64_t)); }
@@ -1102,7 +1273,7 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     hipLaunchKernelGGL(attn_pack_flags_kernel, dim3((unsigned)G), dim3(64), 0, stream, flags, masks, nt);
     MEANT_LAUNCH_CHECK("attn_pack_flags");
   }
-  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, (int)S, H, scale, causal, rot};
+  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, G * (int64_t)H * S, (int)S, H, scale, causal, rot};
   MEANT_RAISE_LDS(attn_bwd_dq_kernel<1>, FWD_LDS);
   MEANT_RAISE_LDS(attn_bwd_dkv_kernel<1>, BWD_DKV_LDS);
   MEANT_RAISE_LDS(attn_bwd_dq_kernel<2>, FWD_LDS2);
