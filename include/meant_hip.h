@@ -156,9 +156,10 @@ int meant_rotary_qk(void* qkv, int64_t T, int64_t S, int H, int Dh, int R, const
  *      the f32 tier, log2 units in the bf16 tier);
  * key_mask: float [G, S] of {0,1} or NULL (adds (1-mask)*-1e9 to the scores);
  * causal: scores[i,j] = -inf for j > i;  scale is the caller's (the reference: 1/sqrt(dim), NOT 1/sqrt(Dh)).
- * bf16: fused flash kernels for Dh = 64 and Dh = 128 (a caller with another head dim < 128 pads every head to 128
- * columns with zeros -- zero rows in the projection weight -- and keeps its own scale; other Dh take a slow fp32
- * detour through `workspace`); f32: materialised scores in `workspace`. */
+ * bf16: fused flash kernels for Dh = 64, 96 (the reference's default: 8 heads at d = 768, meant/meant.py:149) and 128
+ * (a caller with another head dim < 128 pads every head to 128 columns with zeros -- zero rows in the projection
+ * weight -- and keeps its own scale; other Dh take a slow fp32 detour through `workspace`); f32: materialised scores
+ * in `workspace`. */
 size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
 int meant_attn_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H,
                    int Dh, float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,

@@ -59,13 +59,16 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
 // never change, so its two element offsets are computed once (StageOff); per tile only the uniform tile origin moves.
 // Rows past the end of the sequence exist only in a ragged last tile, which gets its own clamped pair.
 struct StageOff { unsigned full[2], last[2]; };
-__device__ __forceinline__ StageOff make_stage_off(int64_t ld, int nrows, int wave, int lane) {
+// ncols < 64 (head dim 96: the second sub-tile has 32 real columns): slots beyond the head re-read one of its first
+// ncols / 8 chunks instead of running into the next head (or, for the last head of the last row, out of the buffer);
+// nothing reads them
+__device__ __forceinline__ StageOff make_stage_off(int64_t ld, int nrows, int wave, int lane, int ncols = 64) {
   StageOff o;
   const int last0 = ((nrows - 1) / KV_TILE) * KV_TILE;              // first row of the last tile
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ swz(r);
+    const int c = ((lane & 7) ^ swz(r)) & (ncols / 8 - 1);
     const int rl = last0 + r < nrows ? r : nrows - 1 - last0;
     o.full[i] = (unsigned)(r * ld + c * 8);
     o.last[i] = (unsigned)(rl * ld + c * 8);
@@ -123,11 +126,13 @@ __device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (
 
 // write a wave's transposed result (acc[b][e]: row = dh 32b + acc_row(e), col = lane&31 = token) to global
 // rows of 64 bf16 through a per-wave LDS patch so that stores are 16 bytes per lane, 128 bytes per row.
+// nblk = 1: only acc[0] / the first 32 columns exist (second half of a 96-wide head)
 __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], float mult, char* patch /* 32 x 144 B */, bf16* __restrict__ dst,
-                                                  int64_t ld, int tok0, int ntok, int lane) {
+                                                  int64_t ld, int tok0, int ntok, int lane, int nblk = 2) {
   const int t = lane & 31;
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 2; ++b) {
+    if (b >= nblk) break;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf16x4 v;
@@ -136,6 +141,7 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], float m
       const int dh = 32 * b + 8 * g4 + 4 * (lane >> 5);
       *reinterpret_cast<bf16x4*>(patch + t * 144 + dh * 2) = v;
     }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -143,7 +149,7 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[2], float m
     const int idx = i * 64 + lane;                 // 32 rows x 8 chunks
     const int r = idx >> 3, c = idx & 7;
     const u32x4 v = *reinterpret_cast<const u32x4*>(patch + r * 144 + c * 16);
-    if (tok0 + r < ntok) *reinterpret_cast<u32x4*>(dst + (int64_t)(tok0 + r) * ld + c * 8) = v;
+    if (tok0 + r < ntok && c < 4 * nblk) *reinterpret_cast<u32x4*>(dst + (int64_t)(tok0 + r) * ld + c * 8) = v;
   }
 }
 
@@ -447,12 +453,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_persist_kernel(FwdArgs a) {
 // forward, one work item per workgroup: the form used without a causal mask, where every item has the same number of
 // tiles and the hardware's dynamic dispatch balances better than a fixed walk (measured: the persistent kernel is
 // 6-11 % slower there and 16-22 % faster under the causal mask, where items are 1-8 tiles long).
-template <int NH>
+template <int HD_>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two buffers of [K: NH sub-tiles | V: NH sub-tiles] (a sub-tile = 64 keys x 64 of the head's 64 NH columns), then
   // bias[2][64] floats, then 4 per-wave patches of 32x144 B (NH = 2: the patches reuse the tile space after the loop)
-  constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;
+  constexpr int HD = HD_, NH = (HD + 63) / 64, KS = HD / 16, OB = HD / 32, BUF_B = 2 * NH * TILE_B;   // sub-tiles, k-steps, 32-column output blocks
   float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_B);
   char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 64 * 4 : smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -472,24 +478,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue).  The first
   // tile is requested before anything else: its round trip is the longest link of the workgroup's start-up chain.
   const StageOff soff = make_stage_off(ld, S, wave, lane);
+  const StageOff soff2 = make_stage_off(ld, S, wave, lane, HD - 64 * (NH - 1));   // last sub-tile: 32 real columns when HD = 96
   auto stage = [&](int t, int buf) {
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      stage64(Kg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, soff);
-      stage64(Vg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff);
+      stage64(Kg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, hf == NH - 1 ? soff2 : soff);
+      stage64(Vg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, hf == NH - 1 ? soff2 : soff);
     }
     if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   stage(0, 0);
 
   // Q fragments (B operand): lane (query = lane&31, half) holds Q[q][16ks + 8*half .. +7]
-  bf16x8 qf[4 * NH];
+  bf16x8 qf[KS];
   {
     int qrow = q0 + (lane & 31);
     qrow = qrow < S ? qrow : S - 1;
     const bf16* qp = base + (int64_t)qrow * ld + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < 4 * NH; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
   const int myq = q0 + (lane & 31);
 
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 
   f32x16 oacc[2 * NH];
 #pragma unroll
-  for (int b = 0; b < 2 * NH; ++b)
+  for (int b = 0; b < OB; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[b][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[sb][e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4 * NH; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
           sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt + (ks >> 2) * TILE_B, 32 * sb, ks & 3, lane), qf[ks], sacc[sb], 0, 0, 0);
       }
       // softmax in the log2 domain: t = s * (scale*log2e) (+ bias), p = exp2(t - m).  Tiles that touch neither the
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
         l_run *= alpha;
         m_run = m_new;
 #pragma unroll
-        for (int b = 0; b < 2 * NH; ++b)
+        for (int b = 0; b < OB; ++b)
 #pragma unroll
           for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
       }
@@ -609,7 +616,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
           for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              oacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), pf[s2], oacc[2 * hf + b], 0, 0, 0);
+              if (2 * hf + b < OB)
+                oacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), pf[s2], oacc[2 * hf + b], 0, 0, 0);
         }
       };
       pv(std::integral_constant<int, 0>{});
@@ -627,14 +635,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   }
   // 1/l differs per lane (query): scale per lane, then transpose through the wave's LDS patch
 #pragma unroll
-  for (int b = 0; b < 2 * NH; ++b)
+  for (int b = 0; b < OB; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[b][e] *= inv_l;
 #pragma unroll
   for (int hf = 0; hf < NH; ++hf) {
     if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(oacc[2 * hf]), 1.0f, patches + wave * (32 * 144),
-                     a.o + (int64_t)g * S * D + h * HD + DH * hf, D, q0, S, lane);
+                     a.o + (int64_t)g * S * D + h * HD + DH * hf, D, q0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
 }
 
@@ -649,10 +657,10 @@ struct BwdArgs {
   RotTables rot;                                     // adjoint rotary on dq / dk when rot.qa != null
 };
 
-template <int NH>
+template <int HD_>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;    // as in the forward
+  constexpr int HD = HD_, NH = (HD + 63) / 64, KS = HD / 16, OB = HD / 32, BUF_B = 2 * NH * TILE_B;   // sub-tiles, k-steps, 32-column output blocks    // as in the forward
   float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_B);
   char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 64 * 4 : smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -673,24 +681,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue).  The first
   // tile is requested before anything else: its round trip is the longest link of the workgroup's start-up chain.
   const StageOff soff = make_stage_off(ld, S, wave, lane);
+  const StageOff soff2 = make_stage_off(ld, S, wave, lane, HD - 64 * (NH - 1));   // last sub-tile: 32 real columns when HD = 96
   auto stage = [&](int t, int buf) {
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      stage64(Kg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, soff);
-      stage64(Vg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff);
+      stage64(Kg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, hf == NH - 1 ? soff2 : soff);
+      stage64(Vg + DH * hf, ld, t * KV_TILE, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, hf == NH - 1 ? soff2 : soff);
     }
     if (wave == 0) glds4(b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
   };
   stage(0, 0);
 
-  bf16x8 qf[4 * NH], dof[4 * NH];
+  bf16x8 qf[KS], dof[KS];
   float delta = 0.f;
   {
     const bf16* qp = base + (int64_t)qrow * ld + 8 * (lane >> 5);
     const bf16* dop = a.dout + ((int64_t)g * S + qrow) * D + h * HD + 8 * (lane >> 5);
     const bf16* op = a.o + ((int64_t)g * S + qrow) * D + h * HD + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < 4 * NH; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
       dof[ks] = *reinterpret_cast<const bf16x8*>(dop + 16 * ks);
       const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 
   f32x16 dqacc[2 * NH];
 #pragma unroll
-  for (int b = 0; b < 2 * NH; ++b)
+  for (int b = 0; b < OB; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[b][e] = 0.f;
 
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4 * NH; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
           sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt + (ks >> 2) * TILE_B, 32 * sb, ks & 3, lane), qf[ks], sacc, 0, 0, 0);
           dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vt + (ks >> 2) * TILE_B, 32 * sb, ks & 3, lane), dof[ks], dpacc, 0, 0, 0);
         }
@@ -792,7 +801,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
           for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              dqacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), dsf[s2], dqacc[2 * hf + b], 0, 0, 0);
+              if (2 * hf + b < OB)
+                dqacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), dsf[s2], dqacc[2 * hf + b], 0, 0, 0);
         }
       };
       body(std::integral_constant<int, 0>{});
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   for (int hf = 0; hf < NH; ++hf) {
     if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(dqacc[2 * hf]), a.scale, patches + wave * (32 * 144),
-                     a.dqkv + (int64_t)g * S * ld + h * HD + DH * hf, ld, q0, S, lane);
+                     a.dqkv + (int64_t)g * S * ld + h * HD + DH * hf, ld, q0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
 }
 
@@ -858,15 +868,15 @@ __device__ __forceinline__ unsigned long long lab_now() {
   return t;
 }
 #endif
-template <int NH>
-__global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdArgs a) {
+template <int HD_>
+__global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef ATTN_LAB_STAMP
   const unsigned long long lab_t0 = lab_now();
   unsigned long long lab_t1 = 0, lab_t2 = 0;
 #endif
   // two buffers of [Q: NH sub-tiles | dO: NH sub-tiles], stats[2][4][64] floats, 4 patches (NH = 2: in the tile space)
-  constexpr int HD = DH * NH, BUF_B = 2 * NH * TILE_B;
+  constexpr int HD = HD_, NH = (HD + 63) / 64, KS = HD / 16, OB = HD / 32, BUF_B = 2 * NH * TILE_B;   // sub-tiles, k-steps, 32-column output blocks
   float* stats = reinterpret_cast<float*>(smem + 2 * BUF_B);
   char* patches = NH == 1 ? smem + 2 * BUF_B + 2 * 4 * 64 * 4 : smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -916,12 +926,12 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
   // the rest of the kernel exists twice, once per variant: the two never join again, so no accumulator is copied
   auto body = [&](auto PLAIN_T) {
   constexpr bool PLAIN = decltype(PLAIN_T)::value;
-  bf16x8 kf[4 * NH], vf[4 * NH];
+  bf16x8 kf[KS], vf[KS];
   {
     const bf16* kp = base + (int64_t)krow * ld + D + 8 * (lane >> 5);
     const bf16* vp = base + (int64_t)krow * ld + 2 * D + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < 4 * NH; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
       vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
     }
@@ -932,7 +942,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
 
   f32x16 dkacc[2 * NH], dvacc[2 * NH];
 #pragma unroll
-  for (int b = 0; b < 2 * NH; ++b)
+  for (int b = 0; b < OB; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dkacc[b][e] = 0.f; dvacc[b][e] = 0.f; }
 
@@ -942,11 +952,13 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
   // per-tile statistics by DMA too: st[0..127] = interleaved (m, log2 l) pairs of the 64 queries (careful kernel),
   // st[128..191] = -(m + log2 l) (plain kernel), st[192..255] = -delta
   const StageOff soff_q = make_stage_off(ld, S, wave, lane), soff_do = make_stage_off(D, S, wave, lane);
+  constexpr int LASTC = HD - 64 * (NH - 1);            // real columns of the last sub-tile (32 when HD = 96)
+  const StageOff soff_q2 = make_stage_off(ld, S, wave, lane, LASTC), soff_do2 = make_stage_off(D, S, wave, lane, LASTC);
   auto stage = [&](int t, int buf) {
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      stage64(base + DH * hf, ld, t * 64, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, soff_q);
-      stage64(dO + DH * hf, D, t * 64, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, soff_do);
+      stage64(base + DH * hf, ld, t * 64, S, smem + buf * BUF_B + hf * TILE_B, wave, lane, hf == NH - 1 ? soff_q2 : soff_q);
+      stage64(dO + DH * hf, D, t * 64, S, smem + buf * BUF_B + (NH + hf) * TILE_B, wave, lane, hf == NH - 1 ? soff_do2 : soff_do);
     }
     if (wave == 0) {
       float* st = stats + buf * 256;
@@ -991,7 +1003,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
         for (int e4 = 0; e4 < 4; ++e4) dpacc[sq][g4 * 4 + e4] = nd[e4];
       }
 #pragma unroll
-      for (int ks = 0; ks < 4 * NH; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 qv = *reinterpret_cast<const bf16x8*>(Qb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
         const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dOb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
         sacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qv, kf[ks], sacc[sq], 0, 0, 0);
@@ -1060,10 +1072,11 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            dvacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[2 * hf + b], 0, 0, 0);
-            dkacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[2 * hf + b], 0, 0, 0);
-          }
+          for (int b = 0; b < 2; ++b)
+            if (2 * hf + b < OB) {
+              dvacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[2 * hf + b], 0, 0, 0);
+              dkacc[2 * hf + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[2 * hf + b], 0, 0, 0);
+            }
       }
     };
     const std::integral_constant<int, 0> B0{};
@@ -1072,16 +1085,29 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
     // scheduling fences bound what hipcc may overlap (without them it hoists every LDS read of the tile to the top and spills
     // a hundred registers): [scores 1 | weights 0] and [products 0 | weights 1] are the two regions where one block's vector
     // arithmetic is meant to sit between the other block's MFMAs
-    scores(B0);
-    __builtin_amdgcn_sched_barrier(0);
-    scores(B1);
-    weights(B0, pf0, dsf0);
-    __builtin_amdgcn_sched_barrier(0);
-    products(B0, pf0, dsf0);
-    weights(B1, pf1, dsf1);
-    __builtin_amdgcn_sched_barrier(0);
-    products(B1, pf1, dsf1);
-    __builtin_amdgcn_sched_barrier(0);
+    if (HD == 64) {
+      scores(B0);
+      __builtin_amdgcn_sched_barrier(0);
+      scores(B1);
+      weights(B0, pf0, dsf0);
+      __builtin_amdgcn_sched_barrier(0);
+      products(B0, pf0, dsf0);
+      weights(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+      products(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // wider heads: one block at a time -- the second block's score / dP accumulators in flight would cost the second
+      // wave per SIMD (96) or spill (128)
+      scores(B0);
+      weights(B0, pf0, dsf0);
+      products(B0, pf0, dsf0);
+      __builtin_amdgcn_sched_barrier(0);
+      scores(B1);
+      weights(B1, pf1, dsf1);
+      products(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
 #ifdef ATTN_LAB_STAMP
@@ -1122,7 +1148,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
   for (int hf = 0; hf < NH; ++hf) {
     if (hf) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(dvacc[2 * hf]), 1.0f, patch, a.dqkv + (int64_t)g * S * ld + 2 * D + h * HD + DH * hf,
-                     ld, key0, S, lane);
+                     ld, key0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
   if (a.rot.ka) rotary_adjoint_regs(reinterpret_cast<f32x16(&)[2]>(dkacc[0]), a.rot.ka, a.rot.kb, a.rot.R, krow, lane);
 #pragma unroll
@@ -1130,7 +1156,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void attn_bwd_dkv_kernel(BwdA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(dkacc[2 * hf]), a.scale, patch, a.dqkv + (int64_t)g * S * ld + D + h * HD + DH * hf,
-                     ld, key0, S, lane);
+                     ld, key0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
 #ifdef ATTN_LAB_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1146,7 +1172,7 @@ constexpr int FWD_LDS = 4 * TILE_B + 2 * 64 * 4 + 4 * 32 * 144;
 // head dim 128 (NH = 2): twice the tile space, the output patches live in it (2 workgroups per CU by LDS)
 constexpr int BWD_DKV_LDS2 = 8 * TILE_B + 2 * 4 * 64 * 4;
 constexpr int FWD_LDS2 = 8 * TILE_B + 2 * 64 * 4;
-__host__ inline bool native_dh(int Dh) { return Dh == DH || Dh == 2 * DH; }
+__host__ inline bool native_dh(int Dh) { return Dh == 64 || Dh == 96 || Dh == 128; }
 
 }  // namespace
 
@@ -1225,12 +1251,19 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   }
   const int nqb = (int)ceil_div(S, 128);
   FwdArgs a{qkv, o, lse, bias2, flags, masks, (int)S, H, scale, causal, (int)G, nqb};
-  MEANT_RAISE_LDS(attn_fwd_kernel<1>, FWD_LDS);
-  MEANT_RAISE_LDS(attn_fwd_kernel<2>, FWD_LDS2);
+  MEANT_RAISE_LDS(attn_fwd_kernel<64>, FWD_LDS);
+  MEANT_RAISE_LDS(attn_fwd_kernel<96>, FWD_LDS2);
+  MEANT_RAISE_LDS(attn_fwd_kernel<128>, FWD_LDS2);
   MEANT_RAISE_LDS(attn_fwd_persist_kernel, FWD_LDS);
-  if (Dh == 2 * DH) {
-    meant_route_hit(ROUTE_ATTN_FWD_D128);
-    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS2, stream, a);
+  if (Dh != DH) {                                      // 96 and 128: two 64-column sub-tiles per operand tile
+    const dim3 grid2((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
+    if (Dh == 96) {
+      meant_route_hit(ROUTE_ATTN_FWD_D96);
+      hipLaunchKernelGGL(attn_fwd_kernel<96>, grid2, dim3(256), FWD_LDS2, stream, a);
+    } else {
+      meant_route_hit(ROUTE_ATTN_FWD_D128);
+      hipLaunchKernelGGL(attn_fwd_kernel<128>, grid2, dim3(256), FWD_LDS2, stream, a);
+    }
     MEANT_LAUNCH_CHECK("attn_fwd");
     return MEANT_OK;
   }
@@ -1243,7 +1276,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
     hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), FWD_LDS, stream, a);
   } else {
     meant_route_hit(ROUTE_ATTN_FWD);
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
   }
   MEANT_LAUNCH_CHECK("attn_fwd");
   return MEANT_OK;
@@ -1274,23 +1307,33 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     MEANT_LAUNCH_CHECK("attn_pack_flags");
   }
   BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, G * (int64_t)H * S, (int)S, H, scale, causal, rot};
-  MEANT_RAISE_LDS(attn_bwd_dq_kernel<1>, FWD_LDS);
-  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<1>, BWD_DKV_LDS);
-  MEANT_RAISE_LDS(attn_bwd_dq_kernel<2>, FWD_LDS2);
-  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<2>, BWD_DKV_LDS2);
+  MEANT_RAISE_LDS(attn_bwd_dq_kernel<64>, FWD_LDS);
+  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<64>, BWD_DKV_LDS);
+  MEANT_RAISE_LDS(attn_bwd_dq_kernel<96>, FWD_LDS2);
+  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<96>, BWD_DKV_LDS2);
+  MEANT_RAISE_LDS(attn_bwd_dq_kernel<128>, FWD_LDS2);
+  MEANT_RAISE_LDS(attn_bwd_dkv_kernel<128>, BWD_DKV_LDS2);
   const dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
-  if (Dh == 2 * DH) {
-    meant_route_hit(ROUTE_ATTN_BWD_D128);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(256), FWD_LDS2, stream, a);
+  if (Dh == 96) {
+    meant_route_hit(ROUTE_ATTN_BWD_D96);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, grid, dim3(256), FWD_LDS2, stream, a);
     MEANT_LAUNCH_CHECK("attn_bwd_dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid, dim3(256), BWD_DKV_LDS2, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, grid, dim3(256), BWD_DKV_LDS2, stream, a);
+    MEANT_LAUNCH_CHECK("attn_bwd_dkv");
+    return MEANT_OK;
+  }
+  if (Dh == 128) {
+    meant_route_hit(ROUTE_ATTN_BWD_D128);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), FWD_LDS2, stream, a);
+    MEANT_LAUNCH_CHECK("attn_bwd_dq");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), BWD_DKV_LDS2, stream, a);
     MEANT_LAUNCH_CHECK("attn_bwd_dkv");
     return MEANT_OK;
   }
   meant_route_hit(ROUTE_ATTN_BWD);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(256), FWD_LDS, stream, a);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), FWD_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd_dq");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(256), BWD_DKV_LDS, stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), BWD_DKV_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd_dkv");
   return MEANT_OK;
 }

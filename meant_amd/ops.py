@@ -500,14 +500,14 @@ class _QKVAttention(torch.autograd.Function):
         return (dx.view(G, S, d) if dx is not None else None), dw, db, None, None, None, None, None
 
 
-NATIVE_HEAD_DIMS = (64, 128)       # what the bf16 MFMA attention kernels take (csrc/attn_bf16.hip)
+NATIVE_HEAD_DIMS = (64, 96, 128)   # what the bf16 MFMA attention kernels take (csrc/attn_bf16.hip); 96 = the reference's default 8 heads
 
 
 def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads, pre=None):
     """pre = (W1, b1) of a Linear applied to x immediately before the projections (composed into them).
 
-    bf16 tier, head dims other than 64 / 128 (the reference classes default to 8 heads: 96 at d = 768): every head is
-    widened to 128 columns by zero rows in the projection weights, so q, k, v come out of the GEMM already padded, the
+    bf16 tier, head dims other than 64 / 96 / 128 (96 = the reference classes' default of 8 heads at d = 768, served
+    natively): every head is widened to 128 columns by zero rows in the projection weights, so q, k, v come out of the GEMM already padded, the
     scores are unchanged (zeros add nothing to q.k, the scale stays 1/sqrt(dim)), and the zero columns of v give zero
     columns of the output, which are dropped again.  The padding is built from the parameters with differentiable ops,
     so their gradients need no special handling."""

@@ -161,7 +161,7 @@ def test_meant_vqa_full_width_vs_oracle(dev, dtype):
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_default_eight_heads_head_dim_96(dev, dtype):
     """the reference's own runs never pass num_heads (default 8 -> head dim 96, rotary dim 48 for the patches): the bf16
-    tier serves it through the widening attention path"""
+    tier serves it on the 96-wide attention kernels"""
     ref, hip = _mk("meant", (768, 768, 4, 64, 64, 16, 2, 2), dict(num_encoders=1), (500, 768), dev)     # num_heads default 8
     r = np.random.RandomState(22)
     ids = t(r.randint(0, 500, (2, 2, 40)).astype("int64"))

@@ -229,8 +229,8 @@ def test_attention_modules_golden(M, O, dev, golden, dtype, name, kind):
 @pytest.mark.parametrize("kind,G,S,H,d", [("pixel", 3, 196, 12, 768), ("xpos", 2, 512, 12, 768), ("xpos", 5, 64, 2, 128),
                                           ("pixel", 2, 4, 2, 128), ("xpos", 3, 100, 4, 256), ("xpos", 2, 1, 2, 128),
                                           ("pixel", 1, 300, 2, 128),
-                                          # head dims 96 (the reference's default 8 heads; padded to 128 in the bf16 tier),
-                                          # 128 (native), 80 (padded)
+                                          # head dims 96 (the reference's default 8 heads: native), 128 (native), 80 (padded to 128
+                                          # in the bf16 tier)
                                           ("xpos", 2, 512, 8, 768), ("pixel", 3, 196, 8, 768), ("xpos", 3, 200, 2, 256),
                                           ("pixel", 2, 130, 1, 128), ("xpos", 2, 100, 4, 320)])
 def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
@@ -284,6 +284,35 @@ def test_text_attention_padding_patterns(M, O, dev, dtype, H, d):
     assert_close(yh, yr, tol["out"] * (1 if dtype == torch.float32 else 4), "y")
     assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
     compare_param_grads(ref, hip, dtype, "xpos")
+
+
+def test_head_dim_96_runs_on_the_native_kernels(M, O, dev):
+    """the reference's default of 8 heads (meant/meant.py:149: Dh = 96 at d = 768) takes the 96-wide instantiation of the
+    flash kernels -- six k-steps for QK^T, three 32-column output blocks, an unpadded [T, 3 * 768] projection buffer --
+    not the zero-padded 128-wide one and not the fp32 detour; checked through the library's route counters, with values
+    against the oracle on a causal padded case and an unmasked ragged one"""
+    from meant_amd import _lib
+    for kind, G, S in (("xpos", 3, 200), ("pixel", 2, 196)):
+        ref, hip = _attn_pair(M, O, kind, 8, 768, dev)
+        rs = np.random.RandomState(S)
+        x = t(rs.standard_normal((G, S, 768)).astype("float32"))
+        dy = t(rs.standard_normal((G, S, 768)).astype("float32"))
+        mask = torch.ones(G, S)
+        mask[0, S // 3:] = 0
+        xq, dyq = x.bfloat16().float(), dy.bfloat16().float()
+        xr = xq.clone().requires_grad_()
+        yr = ref(xr, mask) if kind == "xpos" else ref(xr)
+        yr.backward(dyq)
+        _lib.route_reset()
+        xh = x.to(dev).bfloat16().requires_grad_()
+        yh = hip(xh, mask.to(dev)) if kind == "xpos" else hip(xh)
+        yh.backward(dy.to(dev).bfloat16())
+        assert _lib.route_count("attn_fwd_d96") == 1 and _lib.route_count("attn_bwd_d96") == 1
+        assert _lib.route_count("attn_fwd_d128") == 0 and _lib.route_count("attn_generic") == 0
+        tol = TOL[torch.bfloat16]
+        assert_close(yh, yr, tol["out"] * 4, "y")
+        assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+        compare_param_grads(ref, hip, torch.bfloat16, kind)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
