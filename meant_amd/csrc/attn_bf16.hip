@@ -54,6 +54,24 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 4, 0, 0);
 }
 
+// Work item of a workgroup in a 1-D launch over nx * H * G items (x = 128-row block of the sequence, fastest).  Workgroups are
+// dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), so with the natural order block -> (x, h, g) and nx = 4 the
+// causal text shape gave XCDs 0 and 4 every heaviest block and XCDs 3 and 7 every lightest one: the launch lasted as long
+// as two of the eight XCDs needed (dK/dV: 1.16 waves per SIMD resident on average out of 2).  Here XCD x walks the
+// contiguous item range [x * chunk, (x + 1) * chunk): every XCD gets the same mix, and the blocks of one (g, h) -- which
+// share their K / V or Q / dO tiles -- meet in one L2.
+__device__ __forceinline__ bool attn_item(int nx, int H, int G, int& x, int& h, int& g) {
+  const unsigned N = (unsigned)nx * H * G, id = blockIdx.x, chunk = (N + 7) / 8;
+  const unsigned j = id >> 3, item = (id & 7) * chunk + j;
+  if (j >= chunk || item >= N) return false;
+  x = (int)(item % nx);
+  const unsigned gh = item / nx;
+  h = (int)(gh % H);
+  g = (int)(gh / H);
+  return true;
+}
+__host__ inline unsigned attn_grid(int64_t nx, int H, int64_t G) { return (unsigned)(8 * ((nx * H * G + 7) / 8)); }
+
 // stage a [64 rows][64 cols] bf16 tile: rows row0.. (clamped to nrows-1) of a matrix with row stride ld.
 // 8 pieces of 1 KiB (8 rows each); wave w issues pieces 2w, 2w+1.  A lane's row-in-tile and swizzled 16-byte column
 // never change, so its two element offsets are computed once (StageOff); per tile only the uniform tile origin moves.
@@ -114,6 +132,21 @@ template <int KROW0>
 __device__ __forceinline__ void tr_issue(unsigned tile_addr, const TrOff& t, int b, u32x2& lo, u32x2& hi) {
   lo = lds_read_tr16<KROW0 * 128>(tile_addr + t.o[0][b]);
   hi = lds_read_tr16<KROW0 * 128>(tile_addr + t.o[1][b]);
+}
+
+// row fragment by inline-asm ds_read_b128 (immediate offset): issued where the source says, in a batch, so that the LDS
+// latency is paid once per batch instead of once per MFMA (hipcc pairs every builtin LDS load with an lgkmcnt(0) right in
+// front of its consumer).  The consumer must sit behind lds_wait_frags() on the same registers.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_frag(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return __builtin_bit_cast(bf16x8, r);
+}
+// wait until at most N younger LDS operations are outstanding; names the fragments so that their consumers depend on it
+template <int N>
+__device__ __forceinline__ void lds_wait_frags(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
 // accumulator (32 keys x 32 queries, fp32) -> two bf16 B-operand fragments (k-steps of 16 keys)
@@ -464,9 +497,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
-  const int g = blockIdx.z, h = blockIdx.y;
-  // heaviest (latest) query blocks first under the causal mask
-  const int qb = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+  int g, h, qb;
+  if (!attn_item(a.nqb, H, a.G, qb, h, g)) return;
   const int q0 = qb * 128 + wave * 32;             // this wave's first query
   const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
   const bf16* Kg = base + D;
@@ -647,6 +679,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
 }
 
 
+// Work item of the backward kernels: a PAIR of 128-row blocks (p, nblk - 1 - p) of one (g, h), processed one after the other.
+// Under the causal mask block x has work proportional to x + 1 (dQ) or nblk - x (dK/dV), so single blocks last anything from
+// zero (dead padding) to 8 tiles and the launch kept 1.2 of 2 waves per SIMD resident; pairs are all about equally long
+// and there are half as many launches.  (A persistent work queue was tried instead: the item loop around the body costs
+// ~80 spilled SGPRs and the third wave per SIMD of the dQ kernel.)
+#define ATTN_PAIR_LOOP(FIRST_HEAVY_IS_LAST)                                                               \
+  {                                                                                                       \
+    int p__, h__, g__;                                                                                    \
+    const int npair__ = a.causal ? (a.nblk + 1) / 2 : a.nblk;      /* without the mask all blocks are alike */       \
+    if (!attn_item(npair__, H, a.G, p__, h__, g__)) return;                                               \
+    const int hi__ = a.causal ? a.nblk - 1 - p__ : p__;                                                   \
+    process((FIRST_HEAVY_IS_LAST) ? hi__ : p__, h__, g__);                                                \
+    if (hi__ != p__) {                                                                                    \
+      __syncthreads();                                                                                    \
+      process((FIRST_HEAVY_IS_LAST) ? p__ : hi__, h__, g__);                                              \
+    }                                                                                                     \
+  }
+
 // ------------------------------------------------------------------------------------------------
 // backward, pass 1: dQ (and delta).  Same geometry as the forward.
 struct BwdArgs {
@@ -654,11 +704,12 @@ struct BwdArgs {
   const uint64_t* masks;                             // packed tile masks per group (null when S > 4096)
   int64_t plane;                                     // G*H*S: `delta` holds two planes, -(m + log2 l) and -delta, per (g, h, query)
   int S, H; float scale; int causal;
+  int G, nblk;                                       // groups, 128-row blocks per sequence (work items: ceil(nblk / 2) * H * G pairs)
   RotTables rot;                                     // adjoint rotary on dq / dk when rot.qa != null
 };
 
 template <int HD_>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, HD_ == 64 ? 3 : 2) void attn_bwd_dq_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = HD_, NH = (HD + 63) / 64, KS = HD / 16, OB = HD / 32, BUF_B = 2 * NH * TILE_B;   // sub-tiles, k-steps, 32-column output blocks    // as in the forward
   float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF_B);
@@ -666,8 +717,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
-  const int g = blockIdx.z, h = blockIdx.y;
-  const int qb = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+  auto process = [&](int qb, int h, int g) __attribute__((always_inline)) {
   const int q0 = qb * 128 + wave * 32;
   const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
   const bf16* Kg = base + D;
@@ -819,6 +869,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(dqacc[2 * hf]), a.scale, patches + wave * (32 * 144),
                      a.dqkv + (int64_t)g * S * ld + h * HD + DH * hf, ld, q0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
+  };   // process
+  ATTN_PAIR_LOOP(true)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,8 +934,8 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
-  const int g = blockIdx.z, h = blockIdx.y;
-  const int kb0 = blockIdx.x * 128;                  // block's first key
+  auto process = [&](int kb, int h, int g) __attribute__((always_inline)) {
+  const int kb0 = kb * 128;                          // block's first key
   const int key0 = kb0 + wave * 32;                  // wave's first key
   const int mykey = key0 + (lane & 31);
   const int krow = mykey < S ? mykey : S - 1;
@@ -992,8 +1044,30 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
     const char* dOb = Qb + NH * TILE_B;
     const int qrow0 = 4 * (lane >> 5);                           // + 32 sq + 8 g4 + e4: local query row of element e
     f32x16 sacc[2], dpacc[2];
-    auto scores = [&](auto SQ) {
+    // row fragments of Q and dO for one 32-query block: KS + KS ds_read_b128, issued as one batch
+    unsigned fbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fbase[i] = lds_addr(Qb) + foff[i];
+    auto frags = [&](auto SQ, bf16x8 (&qv)[KS], bf16x8 (&dv)[KS]) {
       constexpr int sq = decltype(SQ)::value;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (HD != 64) {                                    // wider heads: compiler-managed loads (a batch would cost registers they lack)
+          qv[ks] = *reinterpret_cast<const bf16x8*>(Qb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
+          dv[ks] = *reinterpret_cast<const bf16x8*>(dOb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
+        } else if (ks < 4) {
+          qv[ks] = lds_frag<sq * 4096>(fbase[ks & 3]);
+          dv[ks] = lds_frag<sq * 4096 + NH * TILE_B>(fbase[ks & 3]);
+        } else {
+          qv[ks] = lds_frag<sq * 4096 + TILE_B>(fbase[ks & 3]);
+          dv[ks] = lds_frag<sq * 4096 + TILE_B + NH * TILE_B>(fbase[ks & 3]);
+        }
+      }
+    };
+    // YOUNGER = LDS reads issued after this block's fragments that may still be in flight when its MFMAs start
+    auto scores = [&](auto SQ, auto YOUNGER, bf16x8 (&qv)[KS], bf16x8 (&dv)[KS]) {
+      constexpr int sq = decltype(SQ)::value;
+      constexpr int younger = decltype(YOUNGER)::value;
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[sq][e] = 0.f;
 #pragma unroll
@@ -1002,13 +1076,19 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) dpacc[sq][g4 * 4 + e4] = nd[e4];
       }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 qv = *reinterpret_cast<const bf16x8*>(Qb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dOb + sq * 4096 + (ks >> 2) * TILE_B + foff[ks & 3]);
-        sacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qv, kf[ks], sacc[sq], 0, 0, 0);
-        dpacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv, vf[ks], dpacc[sq], 0, 0, 0);
-      }
+      auto kstep = [&](auto KSI) {
+        constexpr int ks = decltype(KSI)::value;
+        if constexpr (ks < KS) {
+          // fragments were issued in the order q0 d0 q1 d1 ...: when at most `younger` + 2 (KS - 1 - ks) reads are outstanding,
+          // this k-step's pair has landed
+          if constexpr (HD == 64) lds_wait_frags<(younger + 2 * (KS - 1 - ks) > 15 ? 15 : younger + 2 * (KS - 1 - ks))>(qv[ks], dv[ks]);
+          sacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qv[ks], kf[ks], sacc[sq], 0, 0, 0);
+          dpacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv[ks], vf[ks], dpacc[sq], 0, 0, 0);
+        }
+      };
+      kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+      kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+      kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{});
     };
     auto weights = [&](auto SQ, bf16x8 (&pf)[2], bf16x8 (&dsf)[2]) {
       constexpr int sq = decltype(SQ)::value;
@@ -1085,10 +1165,15 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
     // scheduling fences bound what hipcc may overlap (without them it hoists every LDS read of the tile to the top and spills
     // a hundred registers): [scores 1 | weights 0] and [products 0 | weights 1] are the two regions where one block's vector
     // arithmetic is meant to sit between the other block's MFMAs
+    const std::integral_constant<int, 0> NONE{};
+    const std::integral_constant<int, 2 * KS> BLOCK{};
+    bf16x8 q0[KS], d0[KS], q1[KS], d1[KS];
     if (HD == 64) {
-      scores(B0);
+      frags(B0, q0, d0);                                   // every row fragment of the tile up front: one LDS latency per tile
+      frags(B1, q1, d1);
+      scores(B0, BLOCK, q0, d0);
       __builtin_amdgcn_sched_barrier(0);
-      scores(B1);
+      scores(B1, NONE, q1, d1);
       weights(B0, pf0, dsf0);
       __builtin_amdgcn_sched_barrier(0);
       products(B0, pf0, dsf0);
@@ -1099,11 +1184,13 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
     } else {
       // wider heads: one block at a time -- the second block's score / dP accumulators in flight would cost the second
       // wave per SIMD (96) or spill (128)
-      scores(B0);
+      frags(B0, q0, d0);
+      scores(B0, NONE, q0, d0);
       weights(B0, pf0, dsf0);
       products(B0, pf0, dsf0);
       __builtin_amdgcn_sched_barrier(0);
-      scores(B1);
+      frags(B1, q1, d1);
+      scores(B1, NONE, q1, d1);
       weights(B1, pf1, dsf1);
       products(B1, pf1, dsf1);
       __builtin_amdgcn_sched_barrier(0);
@@ -1132,7 +1219,7 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
   lab_t2 = lab_now();
   auto lab_out = [&]() {
     if (tid == 0) {
-      const int64_t wg = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const int64_t wg = blockIdx.x;
       if (wg < LAB_MAX_WG) {
         unsigned long long* o = g_lab_stamp + wg * 4;
         o[0] = lab_t1 - lab_t0; o[1] = lab_t2 - lab_t1; o[2] = lab_now() - lab_t2; o[3] = (unsigned long long)(t0 < nt ? nt - t0 : 0);
@@ -1165,6 +1252,8 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
   };
   if (block_plain) body(std::true_type{});
   else body(std::false_type{});
+  };   // process
+  ATTN_PAIR_LOOP(false)
 }
 
 constexpr int BWD_DKV_LDS = 4 * TILE_B + 2 * 4 * 64 * 4 + 4 * 32 * 144;
@@ -1226,8 +1315,8 @@ static int attn_bf16_generic(bool backward, const bf16* qkv, const bf16* o, cons
 
 static int attn_bf16_check(const char* name, int64_t G, int64_t S, int H, int Dh) {
   (void)Dh;
-  MEANT_REQUIRE(G <= 65535 && H <= 65535 && S < (1 << 24), MEANT_ERR_UNSUPPORTED, "%s: G=%lld / H=%d / S=%lld exceed the grid limits",
-                name, (long long)G, H, (long long)S);
+  MEANT_REQUIRE(G <= 65535 && H <= 65535 && S < (1 << 24) && ceil_div(S, 128) * H * G < (1LL << 31) - 8, MEANT_ERR_UNSUPPORTED,
+                "%s: G=%lld / H=%d / S=%lld exceed the grid limits", name, (long long)G, H, (long long)S);
   return MEANT_OK;
 }
 
@@ -1256,7 +1345,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   MEANT_RAISE_LDS(attn_fwd_kernel<128>, FWD_LDS2);
   MEANT_RAISE_LDS(attn_fwd_persist_kernel, FWD_LDS);
   if (Dh != DH) {                                      // 96 and 128: two 64-column sub-tiles per operand tile
-    const dim3 grid2((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
+    const dim3 grid2(attn_grid(nqb, H, G));
     if (Dh == 96) {
       meant_route_hit(ROUTE_ATTN_FWD_D96);
       hipLaunchKernelGGL(attn_fwd_kernel<96>, grid2, dim3(256), FWD_LDS2, stream, a);
@@ -1276,7 +1365,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
     hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), FWD_LDS, stream, a);
   } else {
     meant_route_hit(ROUTE_ATTN_FWD);
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G), dim3(256), FWD_LDS, stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(attn_grid(nqb, H, G)), dim3(256), FWD_LDS, stream, a);
   }
   MEANT_LAUNCH_CHECK("attn_fwd");
   return MEANT_OK;
@@ -1306,14 +1395,16 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     hipLaunchKernelGGL(attn_pack_flags_kernel, dim3((unsigned)G), dim3(64), 0, stream, flags, masks, nt);
     MEANT_LAUNCH_CHECK("attn_pack_flags");
   }
-  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, G * (int64_t)H * S, (int)S, H, scale, causal, rot};
+  BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, G * (int64_t)H * S, (int)S, H, scale, causal, (int)G, (int)ceil_div(S, 128), rot};
   MEANT_RAISE_LDS(attn_bwd_dq_kernel<64>, FWD_LDS);
   MEANT_RAISE_LDS(attn_bwd_dkv_kernel<64>, BWD_DKV_LDS);
   MEANT_RAISE_LDS(attn_bwd_dq_kernel<96>, FWD_LDS2);
   MEANT_RAISE_LDS(attn_bwd_dkv_kernel<96>, BWD_DKV_LDS2);
   MEANT_RAISE_LDS(attn_bwd_dq_kernel<128>, FWD_LDS2);
   MEANT_RAISE_LDS(attn_bwd_dkv_kernel<128>, BWD_DKV_LDS2);
-  const dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)G);
+  const int64_t nblk = ceil_div(S, 128);
+  const dim3 grid(attn_grid(causal ? (nblk + 1) / 2 : nblk, H, G));   // causal: one workgroup per pair of 128-row blocks
+  meant_route_hit(ROUTE_ATTN_BWD);
   if (Dh == 96) {
     meant_route_hit(ROUTE_ATTN_BWD_D96);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, grid, dim3(256), FWD_LDS2, stream, a);
@@ -1330,7 +1421,6 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     MEANT_LAUNCH_CHECK("attn_bwd_dkv");
     return MEANT_OK;
   }
-  meant_route_hit(ROUTE_ATTN_BWD);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), FWD_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd_dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), BWD_DKV_LDS, stream, a);

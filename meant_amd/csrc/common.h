@@ -43,6 +43,8 @@ void meant_set_error(const char* fmt, ...);
 int meant_current_device(void);
 // raise hipFuncAttributeMaxDynamicSharedMemorySize of `kernel` once per DEVICE (the attribute is per device)
 int meant_raise_dyn_lds(const void* kernel, int bytes);
+// workgroups of `kernel` resident per CU at this block size and dynamic LDS size (occupancy API, cached per device)
+int meant_resident_blocks(const void* kernel, int block_threads, size_t dyn_lds);
 #define MEANT_RAISE_LDS(kernel, bytes)                                        \
   do {                                                                        \
     int rc__ = meant_raise_dyn_lds((const void*)(kernel), (int)(bytes));      \

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <unordered_set>
 
 static thread_local char g_err[512] = "";
@@ -32,6 +33,7 @@ namespace {
 struct DeviceState {
   int cus = -1;                                   // -1: not queried yet
   std::unordered_set<const void*> lds_raised;     // kernels whose MaxDynamicSharedMemorySize was set on this device
+  std::unordered_map<const void*, int> resident;  // workgroups of a kernel that fit on one CU (persistent launches)
 };
 std::mutex g_dev_mu;
 DeviceState g_dev[MEANT_MAX_DEVICES];
@@ -66,6 +68,19 @@ int meant_raise_dyn_lds(const void* kernel, int bytes) {
                 hipGetErrorString(e));
   st.lds_raised.insert(kernel);
   return MEANT_OK;
+}
+
+int meant_resident_blocks(const void* kernel, int block_threads, size_t dyn_lds) {
+  const int dev = meant_current_device();
+  if (dev < 0) return 1;
+  std::lock_guard<std::mutex> lock(g_dev_mu);
+  DeviceState& st = g_dev[dev];
+  auto it = st.resident.find(kernel);
+  if (it != st.resident.end()) return it->second;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block_threads, dyn_lds) != hipSuccess || n < 1) n = 1;
+  st.resident.emplace(kernel, n);
+  return n;
 }
 
 // ---- runtime options ------------------------------------------------------------------------------
