@@ -47,9 +47,14 @@ def flops_per_sample(E: int) -> float:
 def flops_per_sample_executed(E: int) -> float:
     """what the kernels here execute: the encoder's Linear(d,d) that feeds q/k/v is composed into the projection
     (meant_amd.modules.COMPOSE_PRE_LINEAR), which removes 2 d^2 FLOPs per token per layer in forward and twice
-    that in backward; everything else as above."""
+    that in backward, and the stacks' final Linear commutes with the mean-pool; everything else as above."""
     import meant_amd.modules as mm
-    saved = 3.0 * E * 2.0 * D * D * L * (S + (IMG // P) ** 2) if mm.COMPOSE_PRE_LINEAR else 0.0
+    per_linear = 3.0 * 2.0 * D * D * L * (S + (IMG // P) ** 2)          # one Linear(d, d) on every token: fwd + dX + dW
+    saved = E * per_linear if mm.COMPOSE_PRE_LINEAR else 0.0
+    # the last Linear of the last layer of each stack is evaluated on the pooled features (meant_amd.modules.POOL_LAST_LINEAR:
+    # mean_s(h W^T + b + x) = mean_s(h) W^T + b + mean_s(x)); what replaces it is S (resp. 196) times smaller
+    if mm.POOL_LAST_LINEAR:
+        saved += per_linear - 3.0 * 2.0 * D * D * L * 2
     return flops_per_sample(E) - saved
 
 

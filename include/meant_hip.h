@@ -67,13 +67,12 @@ int meant_num_cus(void);
  *   "nt_dynamic"       1|0   streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements)
  *   "nt_qkv_split"     1|0   fused q|k|v projection as three L2-resident column passes / one pass
  *   "nt_grid_cap"      0|n   cap the streaming GEMM's grid at n workgroups (tests: many tiles per workgroup, steals)
- *   "attn_persist"    -1|0|1 persistent attention forward: causal only / never / always
- *   "attn_bwd_persist" 1|0   persistent attention backward kernels / one item per workgroup */
+ */
 int meant_set_option(const char* name, int value);
 int meant_get_option(const char* name, int* value);
 /* how many launches took a given kernel route since the last reset ("nt128", "nt256", "nt256s", "nt256s_rot",
- * "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32", "attn_fwd", "attn_fwd_persist", "attn_fwd_d128",
- * "attn_fwd_d96", "attn_bwd", "attn_bwd_persist", "attn_bwd_d128", "attn_bwd_d96", "attn_generic", "attn_cls");
+ * "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32", "attn_fwd", "attn_fwd_d128",
+ * "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96", "attn_generic", "attn_cls");
  * -1 for an unknown name.  Tests use it to prove that a shape reaches the kernel it is meant to exercise. */
 int64_t meant_route_count(const char* route);
 void meant_route_reset(void);

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void attn_prep_mask_kernel(const float* __restr
   if (lane == 0) flags[(int64_t)g * nt + t] = any | (skip << 1);
 }
 
-// packed per-group tile masks for the persistent forward kernel: masks[g] = {bit t: tile t needs the bias / tail path,
+// packed per-group tile masks: masks[g] = {bit t: tile t needs the bias / tail path,
 // bit t: tile t can be skipped} (ntile <= 64).  Two 64-bit words per group that a workgroup fetches with ONE scalar load
 // when it picks up a work item, instead of a vector load + ballots whose latency would sit in the item's start-up chain.
 __global__ __launch_bounds__(64) void attn_pack_flags_kernel(const int* __restrict__ flags, uint64_t* __restrict__ masks, int nt) {
@@ -268,224 +268,28 @@ __device__ __forceinline__ void sload_masks(const uint64_t* p, uint64_t& m0, uin
   m1 = ((uint64_t)v[3] << 32) | v[2];
 }
 
-// Persistent: three workgroups per CU walk a list of work items (group g, head h, 128-query block qb) and treat the
-// K/V tiles of consecutive items as ONE stream through the two-stage DMA pipeline.  Measured on the one-item-per-
-// workgroup form: time per wave-tile = 0.67 us + 2.06 us / (tiles per item) of SIMD time, i.e. ~6 us of wall clock
-// per item go to launch, address set-up, the Q load and the first K/V round trip -- more than the math of the 1-8
-// tiles a causal S = 512 item has.  Here the first K/V tile of the next item is already on its way and its Q fragments
-// are being fetched while the last tile of the current item is computed; an item's metadata (tile masks) is one scalar
-// load.  Items are handed out heaviest first (late query blocks under the causal mask) and the assignment rotates by
-// one every round so that no workgroup keeps drawing the heavy ones.
-__global__ __launch_bounds__(256, 3) void attn_fwd_persist_kernel(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [K0 | V0 | K1 | V1] 32 KiB, then bias[2][64] floats, then 4 per-wave patches of 32x144 B
-  float* bias_s = reinterpret_cast<float*>(smem + 4 * TILE_B);
-  char* patches = smem + 4 * TILE_B + 2 * 64 * 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = a.S, H = a.H, D = H * DH;
-  const int64_t ld = 3 * (int64_t)D;
-  const int ntile = (S + KV_TILE - 1) / KV_TILE;
-  const int nitems = a.nqb * H * a.G, NB = gridDim.x;
-  const float c1 = a.scale * LOG2E;
-  const StageOff soff = make_stage_off(ld, S, wave, lane);
-  const TrOff troff = make_troff(lane);
-  const bool masks_ok = a.masks != nullptr;
-
-  struct Item {                                        // wave-uniform
-    int g, h, qb, nt;
-    const bf16* base;
-    const float* b2g;
-    const int* flg;
-    uint64_t special_mask, skip_mask;
-  };
-  auto tile_flag = [&](const Item& it, int t) -> int {
-    return masks_ok ? (int)((it.special_mask >> t) & 1) | ((int)((it.skip_mask >> t) & 1) << 1) : it.flg[t];
-  };
-  auto decode = [&](int idx, Item& it) {
-    const int qrev = idx % a.nqb, gh = idx / a.nqb;
-    it.h = gh % H;
-    it.g = gh / H;
-    it.qb = a.causal ? a.nqb - 1 - qrev : qrev;        // heaviest (latest) query blocks first under the causal mask
-    it.base = a.qkv + (int64_t)it.g * S * ld + it.h * DH;
-    it.b2g = a.bias2 + (int64_t)it.g * ntile * KV_TILE;
-    it.flg = a.flags + (int64_t)it.g * ntile;
-    it.special_mask = it.skip_mask = 0;
-    if (masks_ok) sload_masks(a.masks + 2 * (int64_t)it.g, it.special_mask, it.skip_mask);
-    int kend = S;
-    if (a.causal) { const int lastq = it.qb * 128 + 127; kend = lastq + 1 < S ? lastq + 1 : S; }
-    it.nt = (kend + KV_TILE - 1) / KV_TILE;
-    while (it.nt > 1 && (tile_flag(it, it.nt - 1) & 2)) --it.nt;   // trailing all-padding tiles contribute exactly 0
-  };
-  // Q fragments by inline-asm loads: hipcc does not see them, so it cannot park a vmcnt(0) right behind a prefetch
-  // (it did: the copy into the live registers was scheduled straight after the loads, draining the DMA issued with
-  // them).  Their consumer always sits behind a __syncthreads(), whose vmcnt(0) covers them.
-  auto load_q = [&](const Item& it, bf16x8 (&q)[4]) {
-    int qrow = it.qb * 128 + wave * 32 + (lane & 31);
-    qrow = qrow < S ? qrow : S - 1;
-    const bf16* qp = it.base + (int64_t)qrow * ld + 8 * (lane >> 5);
-    u32x4 r0, r1, r2, r3;
-    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(qp) : "memory");
-    q[0] = __builtin_bit_cast(bf16x8, r0); q[1] = __builtin_bit_cast(bf16x8, r1);
-    q[2] = __builtin_bit_cast(bf16x8, r2); q[3] = __builtin_bit_cast(bf16x8, r3);
-  };
-  // everything staged inside the loop goes by DMA (a plain LDS store would make hipcc drain the DMA queue)
-  auto stage = [&](const Item& it, int t, int buf) {
-    stage64(it.base + D, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B, wave, lane, soff);
-    stage64(it.base + 2 * D, ld, t * KV_TILE, S, smem + buf * 2 * TILE_B + TILE_B, wave, lane, soff);
-    if (wave == 0) glds4(it.b2g + t * KV_TILE + lane, bias_s + buf * 64);   // the tile's 64 bias values
-  };
-  auto item_index = [&](int round) { return round * NB + (int)((blockIdx.x + round) % NB); };
-
-  int round = 0;
-  if (item_index(0) >= nitems) return;
-  Item cur, nxt;
-  decode(item_index(0), cur);
-  bf16x8 qf[4], qn[4];
-  load_q(cur, qf);
-  int step = 0;                                        // tiles processed so far: the DMA buffer alternates with it
-  stage(cur, 0, 0);
-  __syncthreads();
-
-  for (;;) {
-    const int nidx = item_index(round + 1);
-    const bool has_next = nidx < nitems;
-    if (has_next) decode(nidx, nxt);
-    const int q0 = cur.qb * 128 + wave * 32;           // this wave's first query
-    const int myq = q0 + (lane & 31);
-    f32x16 oacc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[b][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    for (int t = 0; t < cur.nt; ++t, ++step) {
-      const int buf = step & 1;
-      if (t + 1 < cur.nt) stage(cur, t + 1, buf ^ 1);
-      else if (has_next) { stage(nxt, 0, buf ^ 1); load_q(nxt, qn); }
-      const int k0 = t * KV_TILE;
-      const int flag = tile_flag(cur, t);
-      const bool active = !(flag & 2) && (!a.causal || (k0 <= q0 + 31));   // wave-uniform: tile not entirely above the diagonal / all padding
-      if (active && q0 < S) {
-        const char* Kt = smem + buf * 2 * TILE_B;
-        const char* Vt = Kt + TILE_B;
-        // S^T (2 sub-tiles of 32 keys)
-        f32x16 sacc[2];
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) sacc[sb][e] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sb, ks, lane), qf[ks], sacc[sb], 0, 0, 0);
-        }
-        // softmax in the log2 domain: t = s * (scale*log2e) (+ bias), p = exp2(t - m).  Tiles that touch neither the
-        // diagonal, nor padding, nor the end of the sequence (most of them) take the mask-free path: raw maxima, the
-        // scale folded into the exponent.  O and l are rescaled only on tiles where some lane's running max moves.
-        const bool diag = a.causal && (k0 + KV_TILE - 1 > q0);   // tile touches the diagonal for some query of this wave
-        const bool special = diag || (flag & 1);
-        float tmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (!special) {
-#pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tmx[e & 3] = fmaxf(tmx[e & 3], sacc[sb][e]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tmx[e] *= c1;
-        } else {
-#pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const int kl0 = 32 * sb + 8 * g4 + 4 * (lane >> 5);
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + buf * 64 + kl0);
-#pragma unroll
-              for (int e4 = 0; e4 < 4; ++e4) {
-                float tv = fmaf(sacc[sb][g4 * 4 + e4], c1, bv[e4]);
-                if (diag && (k0 + kl0 + e4 > myq)) tv = -INFINITY;
-                sacc[sb][g4 * 4 + e4] = tv;
-                tmx[e4] = fmaxf(tmx[e4], tv);
-              }
-            }
-        }
-        float tmax = fmaxf(fmaxf(tmx[0], tmx[1]), fmaxf(tmx[2], tmx[3]));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        // m_run stays finite for every real query: key 0 is never above the diagonal and biases are finite for key < S
-        if (!__all(tmax <= m_run)) {
-          const float m_new = fmaxf(m_run, tmax);
-          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-          l_run *= alpha;
-          m_run = m_new;
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[b][e] *= alpha;
-        }
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        const float ec = special ? 1.0f : c1;          // special tiles hold scaled + biased scores already
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[sb][e], ec, -m_run));
-            sacc[sb][e] = p;
-            ps[e & 3] += p;
-          }
-        float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run += psum;
-        // O^T += V^T P^T
-        const unsigned vaddr = lds_addr(Vt);
-        auto pv = [&](auto SB) {
-          constexpr int sb = decltype(SB)::value;
-          u32x2 lo[2][2], hi[2][2];
-          tr_issue<32 * sb>(vaddr, troff, 0, lo[0][0], hi[0][0]);
-          tr_issue<32 * sb>(vaddr, troff, 1, lo[0][1], hi[0][1]);
-          tr_issue<32 * sb + 16>(vaddr, troff, 0, lo[1][0], hi[1][0]);
-          tr_issue<32 * sb + 16>(vaddr, troff, 1, lo[1][1], hi[1][1]);
-          bf16x8 pf[2];
-          acc_to_frags(sacc[sb], pf[0], pf[1]);
-          lds_wait_all();
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-              oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(lo[s2][b], hi[s2][b]), pf[s2], oacc[b], 0, 0, 0);
-        };
-        pv(std::integral_constant<int, 0>{});
-        pv(std::integral_constant<int, 1>{});
-      }
-      __syncthreads();
-    }
-
-    if (q0 < S) {
-      const float inv_l = 1.0f / l_run;
-      if (lane < 32 && myq < S) {
-        float* lp = a.lse + (((int64_t)cur.g * H + cur.h) * S + myq) * 2;
-        lp[0] = m_run;                                  // log2-domain statistics (tier-internal layout)
-        lp[1] = __log2f(l_run);
-      }
-      // 1/l differs per lane (query): scale per lane, then transpose through the wave's LDS patch
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[b][e] *= inv_l;
-      store_transposed(oacc, 1.0f, patches + wave * (32 * 144), a.o + (int64_t)cur.g * S * D + cur.h * DH, D, q0, S, lane);
-    }
-    if (!has_next) break;
-    cur = nxt;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
-    ++round;
+// Work item of the forward, dQ and dK/dV kernels: a PAIR of 128-row blocks (p, nblk - 1 - p) of one (g, h), processed one after the other.
+// Under the causal mask block x has work proportional to x + 1 (dQ) or nblk - x (dK/dV), so single blocks last anything from
+// zero (dead padding) to 8 tiles and the launch kept 1.2 of 2 waves per SIMD resident; pairs are all about equally long
+// and there are half as many launches.  (Persistent forms were tried for both directions: a work queue around the backward
+// bodies costs ~80 spilled SGPRs and the dQ kernel's third wave per SIMD; the persistent forward of round 1, which streamed
+// K/V tiles across item boundaries, measures 1.57 ms on the causal text shape against 1.45 ms for pairs, and was removed.)
+#define ATTN_PAIR_LOOP(NBLK, FIRST_HEAVY_IS_LAST)                                                              \
+  {                                                                                                       \
+    int p__, h__, g__;                                                                                    \
+    const int nblk__ = (NBLK);                                                                            \
+    const int npair__ = a.causal ? (nblk__ + 1) / 2 : nblk__;      /* without the mask all blocks are alike */       \
+    if (!attn_item(npair__, H, a.G, p__, h__, g__)) return;                                               \
+    const int hi__ = a.causal ? nblk__ - 1 - p__ : p__;                                                   \
+    process((FIRST_HEAVY_IS_LAST) ? hi__ : p__, h__, g__);                                                \
+    if (hi__ != p__) {                                                                                    \
+      __syncthreads();                                                                                    \
+      process((FIRST_HEAVY_IS_LAST) ? p__ : hi__, h__, g__);                                              \
+    }                                                                                                     \
   }
-}
 
 // ------------------------------------------------------------------------------------------------
-// forward, one work item per workgroup: the form used without a causal mask, where every item has the same number of
-// tiles and the hardware's dynamic dispatch balances better than a fixed walk (measured: the persistent kernel is
-// 6-11 % slower there and 16-22 % faster under the causal mask, where items are 1-8 tiles long).
+// forward
 template <int HD_>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -497,8 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = a.S, H = a.H, D = H * HD;
   const int64_t ld = 3 * (int64_t)D;
-  int g, h, qb;
-  if (!attn_item(a.nqb, H, a.G, qb, h, g)) return;
+  auto process = [&](int qb, int h, int g) __attribute__((always_inline)) {
   const int q0 = qb * 128 + wave * 32;             // this wave's first query
   const bf16* base = a.qkv + (int64_t)g * S * ld + h * HD;
   const bf16* Kg = base + D;
@@ -676,26 +479,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
     store_transposed(reinterpret_cast<const f32x16(&)[2]>(oacc[2 * hf]), 1.0f, patches + wave * (32 * 144),
                      a.o + (int64_t)g * S * D + h * HD + DH * hf, D, q0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
+  };   // process
+  ATTN_PAIR_LOOP(a.nqb, true)
 }
 
-
-// Work item of the backward kernels: a PAIR of 128-row blocks (p, nblk - 1 - p) of one (g, h), processed one after the other.
-// Under the causal mask block x has work proportional to x + 1 (dQ) or nblk - x (dK/dV), so single blocks last anything from
-// zero (dead padding) to 8 tiles and the launch kept 1.2 of 2 waves per SIMD resident; pairs are all about equally long
-// and there are half as many launches.  (A persistent work queue was tried instead: the item loop around the body costs
-// ~80 spilled SGPRs and the third wave per SIMD of the dQ kernel.)
-#define ATTN_PAIR_LOOP(FIRST_HEAVY_IS_LAST)                                                               \
-  {                                                                                                       \
-    int p__, h__, g__;                                                                                    \
-    const int npair__ = a.causal ? (a.nblk + 1) / 2 : a.nblk;      /* without the mask all blocks are alike */       \
-    if (!attn_item(npair__, H, a.G, p__, h__, g__)) return;                                               \
-    const int hi__ = a.causal ? a.nblk - 1 - p__ : p__;                                                   \
-    process((FIRST_HEAVY_IS_LAST) ? hi__ : p__, h__, g__);                                                \
-    if (hi__ != p__) {                                                                                    \
-      __syncthreads();                                                                                    \
-      process((FIRST_HEAVY_IS_LAST) ? p__ : hi__, h__, g__);                                              \
-    }                                                                                                     \
-  }
 
 // ------------------------------------------------------------------------------------------------
 // backward, pass 1: dQ (and delta).  Same geometry as the forward.
@@ -870,7 +657,7 @@ __global__ __launch_bounds__(256, HD_ == 64 ? 3 : 2) void attn_bwd_dq_kernel(Bwd
                      a.dqkv + (int64_t)g * S * ld + h * HD + DH * hf, ld, q0, S, lane, OB - 2 * hf >= 2 ? 2 : 1);
   }
   };   // process
-  ATTN_PAIR_LOOP(true)
+  ATTN_PAIR_LOOP(a.nblk, true)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1253,7 +1040,7 @@ __global__ __launch_bounds__(256, HD_ <= 96 ? 2 : 1) void attn_bwd_dkv_kernel(Bw
   if (block_plain) body(std::true_type{});
   else body(std::false_type{});
   };   // process
-  ATTN_PAIR_LOOP(false)
+  ATTN_PAIR_LOOP(a.nblk, false)
 }
 
 constexpr int BWD_DKV_LDS = 4 * TILE_B + 2 * 4 * 64 * 4 + 4 * 32 * 144;
@@ -1343,9 +1130,8 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   MEANT_RAISE_LDS(attn_fwd_kernel<64>, FWD_LDS);
   MEANT_RAISE_LDS(attn_fwd_kernel<96>, FWD_LDS2);
   MEANT_RAISE_LDS(attn_fwd_kernel<128>, FWD_LDS2);
-  MEANT_RAISE_LDS(attn_fwd_persist_kernel, FWD_LDS);
   if (Dh != DH) {                                      // 96 and 128: two 64-column sub-tiles per operand tile
-    const dim3 grid2(attn_grid(nqb, H, G));
+    const dim3 grid2(attn_grid(causal ? (nqb + 1) / 2 : nqb, H, G));
     if (Dh == 96) {
       meant_route_hit(ROUTE_ATTN_FWD_D96);
       hipLaunchKernelGGL(attn_fwd_kernel<96>, grid2, dim3(256), FWD_LDS2, stream, a);
@@ -1356,17 +1142,8 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
     MEANT_LAUNCH_CHECK("attn_fwd");
     return MEANT_OK;
   }
-  const int persist = meant_opt(MEANT_OPT_ATTN_PERSIST);   // -1: causal only
-  if (persist == 1 || (persist == -1 && causal)) {
-    meant_route_hit(ROUTE_ATTN_FWD_PERSIST);
-    // persistent grid: as many workgroups as are resident at once (3 per CU by LDS and registers), never more than items
-    const int64_t nitems = (int64_t)nqb * H * G;
-    const int64_t cap = (int64_t)meant_num_cus() * 3;
-    hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), FWD_LDS, stream, a);
-  } else {
-    meant_route_hit(ROUTE_ATTN_FWD);
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(attn_grid(nqb, H, G)), dim3(256), FWD_LDS, stream, a);
-  }
+  meant_route_hit(ROUTE_ATTN_FWD);
+  hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(attn_grid(causal ? (nqb + 1) / 2 : nqb, H, G)), dim3(256), FWD_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_fwd");
   return MEANT_OK;
 }

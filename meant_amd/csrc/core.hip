@@ -12,7 +12,6 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
-#include <unordered_map>
 #include <unordered_set>
 
 static thread_local char g_err[512] = "";
@@ -33,7 +32,6 @@ namespace {
 struct DeviceState {
   int cus = -1;                                   // -1: not queried yet
   std::unordered_set<const void*> lds_raised;     // kernels whose MaxDynamicSharedMemorySize was set on this device
-  std::unordered_map<const void*, int> resident;  // workgroups of a kernel that fit on one CU (persistent launches)
 };
 std::mutex g_dev_mu;
 DeviceState g_dev[MEANT_MAX_DEVICES];
@@ -70,19 +68,6 @@ int meant_raise_dyn_lds(const void* kernel, int bytes) {
   return MEANT_OK;
 }
 
-int meant_resident_blocks(const void* kernel, int block_threads, size_t dyn_lds) {
-  const int dev = meant_current_device();
-  if (dev < 0) return 1;
-  std::lock_guard<std::mutex> lock(g_dev_mu);
-  DeviceState& st = g_dev[dev];
-  auto it = st.resident.find(kernel);
-  if (it != st.resident.end()) return it->second;
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block_threads, dyn_lds) != hipSuccess || n < 1) n = 1;
-  st.resident.emplace(kernel, n);
-  return n;
-}
-
 // ---- runtime options ------------------------------------------------------------------------------
 namespace {
 struct OptionDef { const char* name; const char* env; int dflt; };
@@ -90,9 +75,7 @@ struct OptionDef { const char* name; const char* env; int dflt; };
 const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"nt_stream", "MEANT_NT_STREAM", 1},           // 0: one-tile-per-workgroup 256x256 NT kernel instead of the streaming one
     {"nt_dynamic", "MEANT_NT_DYNAMIC", 1},         // 0: fixed persistent tile walk; 1: per-XCD counters; 2: draw but ignore (lab)
-    {"attn_persist", "MEANT_ATTN_PERSIST", -1},    // forward: -1 causal only, 0 never, 1 always
     {"deterministic", "MEANT_DETERMINISTIC", 0},   // 1: parameter gradients are bit-reproducible (ordered reductions, no float atomics)
-    {"attn_bwd_persist", "MEANT_ATTN_BWD_PERSIST", 1},
     {"nt_qkv_split", "MEANT_NT_QKV_SPLIT", 1},
     {"nt_grid_cap", "MEANT_NT_GRID_CAP", 0},       // tests: cap the streaming GEMM's grid (0 = one workgroup per CU)
 };
@@ -139,7 +122,7 @@ extern "C" int meant_get_option(const char* name, int* value) {
 namespace {
 const char* const k_routes[MEANT_ROUTE_COUNT] = {
     "nt128", "nt256", "nt256s", "nt256s_rot", "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32",
-    "attn_fwd", "attn_fwd_persist", "attn_fwd_d128", "attn_fwd_d96", "attn_bwd", "attn_bwd_persist", "attn_bwd_d128", "attn_bwd_d96",
+    "attn_fwd", "attn_fwd_d128", "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96",
     "attn_generic", "attn_cls",
 };
 std::atomic<long long> g_route[MEANT_ROUTE_COUNT];

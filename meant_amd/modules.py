@@ -35,6 +35,12 @@ from ._lib import EPI_NONE, EPI_GELU, EPI_SIGMOID
 # run the two Linears separately, exactly as the reference's module list does.
 COMPOSE_PRE_LINEAR = True
 
+# The last Linear (+ residual) of the LAST encoder layer of a stack feeds nothing but the sequence mean-pool
+# (meant/meant.py:231, meant_vision.py:159, meant_tweet.py:161, meant_vqa.py:228): mean_s(h W^T + b + x) is evaluated as
+# mean_s(h) W^T + b + mean_s(x) (ops.pool_linear_cat) -- same function, same gradients, three token-sized GEMMs less per
+# stack.  Set to False to run the module list literally.
+POOL_LAST_LINEAR = True
+
 # Run the vision stack of `meant` on a second HIP stream, concurrently with the language stack
 # (MEANT_TWO_STREAMS=0 in the environment turns it off).
 import os as _os
@@ -256,7 +262,8 @@ class visionEncoder(nn.Module):
         self.encode = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), atten, RMSNorm(dim), Linear(dim, dim)])
         self.encode2 = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), nn.GELU(), RMSNorm(dim), Linear(dim, dim)])
 
-    def forward(self, input):
+    def forward(self, input, pool: bool = False):
+        """pool=True: return (h, res) instead of encode2[-1](h) + res, for ops.pool_linear_cat"""
         e, e2 = self.encode, self.encode2
         n, res = ops.rmsnorm_fork(input, e[0].scale, e[0].eps)      # residual gradient is folded into this norm's backward
         if COMPOSE_PRE_LINEAR and e[1].bias is not None:
@@ -267,6 +274,8 @@ class visionEncoder(nn.Module):
         x1 = e[4](h, residual=res)
         n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
         h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
+        if pool:
+            return h, res
         return e2[4](h, residual=res)
 
 
@@ -282,7 +291,8 @@ class languageEncoder(nn.Module):
         self.encode = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), att, RMSNorm(dim), nn.Dropout(dropout), Linear(dim, dim)])
         self.encode2 = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), nn.GELU(), RMSNorm(dim), nn.Dropout(), Linear(dim, dim)])
 
-    def forward(self, input, attention_mask=None):
+    def forward(self, input, attention_mask=None, pool: bool = False):
+        """pool=True: return (h, res) instead of encode2[-1](h) + res, for ops.pool_linear_cat"""
         e, e2 = self.encode, self.encode2
         p1 = e[4].p if self.training else 0.0
         p2 = e2[4].p if self.training else 0.0
@@ -295,6 +305,8 @@ class languageEncoder(nn.Module):
         x1 = e[5](h, residual=res)
         n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
         h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, _seed() if p2 > 0 else 0)
+        if pool:
+            return h, res
         return e2[5](h, residual=res)
 
 
@@ -347,15 +359,41 @@ class _PatchEmbed(nn.Sequential):
         return self[1](self[0](images))
 
 
-def _run_encoder(enc, x, *args, checkpoint: bool = False):
+def _run_encoder(enc, x, *args, checkpoint: bool = False, **kw):
     """one encoder layer, optionally under activation recomputation: with `model.activation_checkpointing = True` only
     the layer input is kept and the layer is re-run in backward (torch.utils.checkpoint restores the CPU RNG state, from
     which the dropout seeds are drawn, so the recomputed masks are the forward's).  At the reference's CLI default of
     12 encoder layers, 128 samples per GPU would otherwise save ~330 GB of activations."""
     if checkpoint and torch.is_grad_enabled() and x.requires_grad:
         from torch.utils.checkpoint import checkpoint as _ckpt
-        return _ckpt(enc, x, *args, use_reentrant=False, preserve_rng_state=True)
-    return enc(x, *args)
+        return _ckpt(enc, x, *args, use_reentrant=False, preserve_rng_state=True, **kw)
+    return enc(x, *args, **kw)
+
+
+def _run_stack(encoders, x, *args, checkpoint: bool = False):
+    """all encoder layers of one stack; returns either the token tensor, or -- with POOL_LAST_LINEAR -- the
+    (h, res, weight, bias) part that ops.pool_linear_cat pools"""
+    n = len(encoders)
+    for i, enc in enumerate(encoders):
+        last = enc.encode2[-1]
+        if POOL_LAST_LINEAR and i == n - 1 and isinstance(last, Linear):
+            h, res = _run_encoder(enc, x, *args, checkpoint=checkpoint, pool=True)
+            return (h, res, last.weight, last.bias)
+        x = _run_encoder(enc, x, *args, checkpoint=checkpoint)
+    return x
+
+
+def _pool_parts(*stacks):
+    """stacks: outputs of _run_stack (a part tuple or a token tensor) -> pooled, concatenated features [G, sum d]"""
+    if all(isinstance(st, tuple) for st in stacks):
+        return ops.pool_linear_cat(list(stacks))
+    toks = []
+    for st in stacks:
+        if isinstance(st, tuple):                         # mixed: finish this stack the literal way
+            h, res, w, b = st
+            st = ops.linear(h, w, b, residual=res)
+        toks.append(st)
+    return ops.meanpool_cat(*toks)
 
 
 def _embed(mods, ids, dtype):
@@ -417,18 +455,17 @@ class meant(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
-                for enc in self.visionEncoders:
-                    img = _run_encoder(enc, img, checkpoint=ck)
-        for enc in self.languageEncoders:
-            words = _run_encoder(enc, words, attention_mask, checkpoint=ck)
+                img = _run_stack(self.visionEncoders, img, checkpoint=ck)
+        words = _run_stack(self.languageEncoders, words, attention_mask, checkpoint=ck)
         if side is not None:
             main.wait_stream(side)
-            img.record_stream(main)
+            for tt in (img if isinstance(img, tuple) else (img,)):
+                if tt is not None and tt.is_cuda:
+                    tt.record_stream(main)
         else:
             img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
-            for enc in self.visionEncoders:
-                img = _run_encoder(enc, img, checkpoint=ck)
-        fused = ops.meanpool_cat(words, img).view(B, self.lag, self.dim)
+            img = _run_stack(self.visionEncoders, img, checkpoint=ck)
+        fused = _pool_parts(words, img).view(B, self.lag, self.dim)
         for enc in self.temporal_encoding:
             fused = enc(fused)
         return _head(self.mlpHead, fused).squeeze(dim=1).float()
@@ -455,9 +492,8 @@ class meant_vision(nn.Module):
         dt = resolve_compute_dtype(self, images)
         B, L = images.shape[0], images.shape[1]
         img = self.patchEmbed(images.reshape(B * L, *images.shape[2:]), dt)
-        for enc in self.visionEncoders:
-            img = enc(img)
-        fused = ops.meanpool_cat(img).view(B, L, self.dim)
+        img = _run_stack(self.visionEncoders, img)
+        fused = _pool_parts(img).view(B, L, self.dim)
         for enc in self.temporal_encoding:
             fused = enc(fused)
         return _head(self.mlpHead, fused).squeeze(dim=1).float()
@@ -482,9 +518,8 @@ class meant_tweet(nn.Module):
         B = tweets.shape[0]
         words = _embed(self.embedding, tweets.reshape(B * self.lag, tweets.shape[2]), dt)
         attention_mask = attention_mask.reshape(B * self.lag, attention_mask.shape[2])     # required, as in :150
-        for enc in self.languageEncoders:
-            words = enc(words, attention_mask=attention_mask)
-        fused = ops.meanpool_cat(words).view(B, self.lag, self.dim)
+        words = _run_stack(self.languageEncoders, words, attention_mask)
+        fused = _pool_parts(words).view(B, self.lag, self.dim)
         for enc in self.temporal_encoding:
             fused = enc(fused)
         return _head(self.mlpHead, fused).squeeze(dim=1).float()
@@ -515,12 +550,10 @@ class meant_vqa(nn.Module):
     def forward(self, tweets, images, attention_mask=None):
         dt = resolve_compute_dtype(self, images)
         words = _embed(self.embedding, tweets, dt)
-        for enc in self.languageEncoders:
-            words = enc(words, attention_mask)
+        words = _run_stack(self.languageEncoders, words, attention_mask)
         img = self.patchEmbed(images, dt)
-        for enc in self.visionEncoders:
-            img = enc(img)
-        fused = ops.meanpool_cat(words, img)
+        img = _run_stack(self.visionEncoders, img)
+        fused = _pool_parts(words, img)
         return _head(self.mlpHead, fused).float()
 
 

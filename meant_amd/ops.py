@@ -630,6 +630,74 @@ def meanpool_cat(a, b=None):
     return _MeanPoolCat.apply(a, b, torch.float32 if TAIL_FP32 else a.dtype)
 
 
+class _PoolLinearCat(torch.autograd.Function):
+    """torch.cat([mean_s(h_a W_a^T + b_a + x_a), mean_n(h_b W_b^T + b_b + x_b)], -1): the LAST Linear (+ residual) of the last
+    encoder layer of each stack followed by the sequence mean-pool (meant/meant.py:74 / :120 -> :231), evaluated as
+    mean_s(h) W^T + b + mean_s(x) -- a per-token affine map commutes with the mean over tokens.  Same function and
+    gradients; the [tokens, d] x [d, d] GEMM, its input-gradient GEMM and its weight-gradient GEMM (3 of the ~16 big GEMMs
+    per stack at one encoder layer) become [groups, d] products, and their [tokens, d] gradients are row broadcasts.
+    Parts: (h [G, S, d], x [G, S, d], W [d, d], b [d]); the second part is optional.  The pooled arithmetic is fp32 in
+    both tiers (fp32 means, exact-f32 MFMA products on the master weights: [groups, d] is tiny), rounded once to
+    `out_dtype`, the dtype of everything after the pooling (see TAIL_FP32)."""
+
+    @staticmethod
+    def forward(ctx, out_dtype, *flat):
+        parts = [flat[i:i + 4] for i in range(0, len(flat), 4)]
+        _need_gpu(*[t for p in parts for t in p])
+        G = parts[0][0].shape[0]
+        widths = [p[2].shape[0] for p in parts]
+        Dt = sum(widths)
+        dev = parts[0][0].device
+        out = torch.empty((G, Dt), device=dev, dtype=torch.float32)
+        xm = torch.empty((G, Dt), device=dev, dtype=torch.float32)    # mean_s(x_p), laid out like `out` (same row stride)
+        saved, off = [], 0
+        for (h, x, W, b), N in zip(parts, widths):
+            h, x = _c(h), _c(x)
+            assert h.shape[0] == G and x.shape == h.shape[:2] + (N,) and h.dtype == x.dtype
+            S, K = h.shape[1], h.shape[2]
+            hm = torch.empty((G, K), device=dev, dtype=torch.float32)
+            check(lib.meant_meanpool_fwd(_p(h), _p(hm), K, 0, G, S, K, _dt(h), F32, _stream()), "meanpool_fwd")
+            check(lib.meant_meanpool_fwd(_p(x), _p(xm), Dt, off, G, S, N, _dt(x), F32, _stream()), "meanpool_fwd")
+            w_f = _c(W.detach().float())
+            bias_f = _c(b.detach().float()) if b is not None else None
+            check(lib.meant_linear_fwd(_p(hm), K, _p(w_f), _p(bias_f), xm.data_ptr() + off * 4, Dt, out.data_ptr() + off * 4, Dt, None,
+                                       G, N, K, EPI_RESIDUAL, F32, _stream()), "linear_fwd")
+            saved.append((hm, W, b is not None, h.shape, h.dtype, off))
+            off += N
+        ctx.parts = saved
+        return cast(out, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = cast(_c(dout), torch.float32)
+        G, Dt = dout.shape
+        grads = [None]
+        for hm, W, has_b, hshape, hdt, off in ctx.parts:
+            N, K = W.shape
+            S = hshape[1]
+            dy_ptr = dout.data_ptr() + off * 4                              # [G, N] slice of dout, row stride Dt
+            dti = F32 if hdt == torch.float32 else BF16
+            wT = weights.get((W,), torch.float32, True)                    # [K, N]
+            dhm = torch.empty((G, K), device=dout.device, dtype=torch.float32)
+            check(lib.meant_linear_bwd_dx(dy_ptr, Dt, _p(wT), _p(dhm), K, G, N, K, F32, _stream()), "linear_bwd_dx")
+            dw = torch.zeros((N, K), device=dout.device, dtype=torch.float32)
+            db = torch.zeros(N, device=dout.device, dtype=torch.float32) if has_b else None
+            check(lib.meant_linear_bwd_dw(dy_ptr, Dt, _p(hm), K, _p(dw), _p(db), G, N, K, F32, None, 0, _stream()), "linear_bwd_dw")
+            dh = torch.empty(hshape, device=dout.device, dtype=hdt)         # every token of a group gets d(mean h) / S
+            check(lib.meant_meanpool_bwd(_p(dhm), K, 0, _p(dh), G, S, K, dti, F32, _stream()), "meanpool_bwd")
+            dx = torch.empty(hshape[:2] + (N,), device=dout.device, dtype=hdt)
+            check(lib.meant_meanpool_bwd(_p(dout), Dt, off, _p(dx), G, S, N, dti, F32, _stream()), "meanpool_bwd")
+            grads += [dh, dx, dw, db]
+        return tuple(grads)
+
+
+def pool_linear_cat(parts):
+    """parts: [(h, x, weight, bias), ...] (one or two): cat_p(mean_tokens(h_p W_p^T + b_p + x_p)) -> [G, sum d_p]"""
+    out_dtype = torch.float32 if TAIL_FP32 else parts[0][0].dtype
+    flat = [t for p in parts for t in p]
+    return _PoolLinearCat.apply(out_dtype, *flat)
+
+
 class _AddRowVec(torch.autograd.Function):
     """x[b, l, :] + v[0, l, :]  (temp_embedding, meant/meant.py:141-142)."""
 

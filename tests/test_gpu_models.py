@@ -389,6 +389,47 @@ def test_activation_checkpointing_same_gradients(dev):
         assert (g0 - g1).abs().max().item() <= 1e-5 * max(1.0, g0.abs().max().item()), k
 
 
+@pytest.mark.parametrize("cls", ["meant", "meant_vqa", "meant_tweet", "meant_vision"])
+def test_pooled_last_linear_equals_literal_module_list(dev, monkeypatch, cls):
+    """modules.POOL_LAST_LINEAR evaluates mean_s(h W^T + b + x) of the last encoder layer (meant/meant.py:74,120 -> :231) as
+    mean_s(h) W^T + b + mean_s(x): outputs and every parameter gradient must equal the literal Linear -> add -> mean-pool
+    sequence (fp32 tier: to rounding), for two stacks, one stack, ragged token counts (S = 24 vs n = 6) and two layers"""
+    import meant_amd as M
+    import meant_amd.modules as mm
+    torch.manual_seed(3)
+    emb = torch.nn.Embedding(50, 128)
+    if cls == "meant":
+        m = M.meant(128, 192, 4, 32, 48, 16, 2, 3, emb, num_heads=2, num_encoders=2, channels=4)
+    elif cls == "meant_vqa":
+        m = M.meant_vqa(128, 128, 4, 32, 48, 16, 1, 5, emb, num_heads=2, num_encoders=1, channels=4)
+    elif cls == "meant_tweet":
+        m = M.meant_tweet(128, 4, 2, 3, emb, num_heads=2, num_encoders=1)
+    else:
+        m = M.meant_vision(128, 4, 32, 48, 16, 2, 3, num_heads=2, num_encoders=2, channels=4)
+    m = m.to(dev).eval()
+    rs = np.random.RandomState(8)
+    lag = 1 if cls == "meant_vqa" else 2
+    ids = torch.from_numpy(rs.randint(0, 50, (3, lag, 24))).to(dev)
+    img = torch.from_numpy(rs.standard_normal((3, lag, 4, 32, 48)).astype("float32")).to(dev)
+    mask = torch.ones(3, lag, 24, device=dev)
+    mask[1, :, 17:] = 0
+    if cls == "meant_vqa":
+        ids, img, mask = ids[:, 0], img[:, 0], mask[:, 0]
+    args = {"meant": (ids, img, mask), "meant_vqa": (ids, img, mask), "meant_tweet": (ids, mask), "meant_vision": (img,)}[cls]
+    res = []
+    for pooled in (False, True):
+        monkeypatch.setattr(mm, "POOL_LAST_LINEAR", pooled)
+        m.zero_grad(set_to_none=True)
+        out = m(*args)
+        (out * torch.arange(1, out.numel() + 1, device=dev).view_as(out)).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 2e-6
+    assert res[0][1].keys() == res[1][1].keys()
+    for k, g0 in res[0][1].items():
+        g1 = res[1][1][k]
+        assert (g0 - g1).abs().max().item() <= 2e-5 * max(1.0, g0.abs().max().item()), k
+
+
 def test_fp32_tail_switch(golden, dev, monkeypatch):
     """ops.TAIL_FP32 = True keeps the temporal encoder and the head in fp32 inside the bf16 tier (the default lets them follow
     the tier): same gates, and the pooled features really are fp32"""
