@@ -64,7 +64,8 @@ int meant_num_cus(void);
  *   "deterministic"    0|1   parameter gradients (dW, dbias) by ordered reductions instead of float atomics: two runs
  *                            on the same inputs are bit-identical; meant_linear_bwd_dw then needs its workspace
  *   "nt_stream"        1|0   streaming 256x256 NT GEMM / one tile per workgroup           (A/B measurements)
- *   "nt_dynamic"       1|0   streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements)
+ *   "nt_dynamic"       1|0|3 streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements) /
+ *                            only XCD 0 uses its own counter, all other tiles go through the steal path (tests)
  *   "nt_qkv_split"     1|0   fused q|k|v projection as three L2-resident column passes / one pass
  *   "nt_grid_cap"      0|n   cap the streaming GEMM's grid at n workgroups (tests: many tiles per workgroup, steals)
  */
@@ -96,6 +97,26 @@ int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const f
                       float* dscale, int64_t rows, int64_t d, float eps, float drop_p, uint64_t seed,
                       const void* dres, const void* gelu_pre, int dtype, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* ---- RMSNorm beside the sequence mean-pool -------- utils/rms_norm.py:40-57 + meant/meant.py:74,120 -> :231
+ * The last RMSNorm of the last encoder layer has one consumer left once that layer's final Linear is evaluated on the
+ * pooled features (mean_s(h W^T + b + x) = mean_s(h) W^T + b + mean_s(x)): the mean over the group_rows tokens of a
+ * sequence.  meant_rmsnorm_fwd_pooled writes that mean to pooled[g, :] (float [rows / group_rows, d]; ordered sums, bit-reproducible):
+ *   pool_input == 0: of y = dropout(RMSNorm(x)) -- y is NOT written (pass NULL);
+ *   pool_input != 0: of x, the residual operand -- y is written as usual.
+ * meant_rmsnorm_bwd_pooled is meant_rmsnorm_bwd with dy (dy_pooled != 0) and / or dres (dres_pooled != 0) given as the
+ * float [groups, d] gradient of the pooled features: row r receives g[r / group_rows] / group_rows, no [rows, d]
+ * broadcast is materialised.  Supported where meant_rmsnorm_pooled_ok(rows, d, group_rows) != 0 (the packed widths,
+ * d = 768 among them, and group_rows a multiple of the rows a wave packs); the caller falls back to the unfused ops
+ * otherwise. */
+int meant_rmsnorm_pooled_ok(int64_t rows, int64_t d, int64_t group_rows);
+int meant_rmsnorm_fwd_pooled(const void* x, const float* scale, void* y, float* rinv, float* pooled, int64_t rows,
+                             int64_t d, int64_t group_rows, int pool_input, float eps, float drop_p, uint64_t seed,
+                             int dtype, void* stream);
+int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv,
+                             void* dx, float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps,
+                             float drop_p, uint64_t seed, const void* dres, int dres_pooled, const void* gelu_pre,
+                             int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm (heads of meant_vision / meant_tweet) ----- meant/meant_vision.py:147
  * stats: float [rows, 2] (mean, rstd). */

@@ -486,7 +486,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       const bool reading = dynamic && kt == 5;
       if (reading) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(mail) : "v"(mailbox) : "memory");
       const bool drawer = dynamic && kt == 3 && wave == 4 && lane == 0;
-      if (drawer) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(&sched->next[xcd]), "v"(1u) : "memory");
+      // mode 3 (tests): only XCD 0 draws from its own counter; everybody else behaves as if theirs had run dry, so that every
+      // tile of the other seven counters is handed out by the steal path below
+      const bool own = !(mode == 3 && xcd != 0);
+      if (drawer && own) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(&sched->next[xcd]), "v"(1u) : "memory");
       const bool more2 = in2 || has_next;
       if (issuer && !(DBG & 1)) {
         if (in1) stage(pB + (int64_t)(kt + 1) * BK, oB, a.ldb, s3);
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       asm volatile("" : "+v"(mail), "+v"(ticket) : : "memory");
       // tile draw, part 2: the answers are here
       if (drawer) {                                    // K-step 3: resolve and publish (acknowledged by the end of step 4)
-        int id = tile_of(xcd, (unsigned)CH + ticket);
+        int id = own ? tile_of(xcd, (unsigned)CH + ticket) : ntiles;
         if (id >= ntiles) {                            // this XCD is dry: look at the others' counters, take from one with work left
           unsigned seen[8];
 #pragma unroll

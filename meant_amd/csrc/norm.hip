@@ -216,15 +216,114 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const 
   }
 }
 
-template <typename T, int C>
+// Pooled form: the consumer of this norm (POOL = 1) or of its input (POOL = 2) is the sequence mean-pool (meant/meant.py:231).
+// pooled[g, :] (float) = mean over the `group_rows` rows of group g of y (POOL = 1: y itself is not written at all -- it has
+// no other reader once the stack's last Linear is evaluated on the pooled features) or of x (POOL = 2: the residual
+// operand).  A workgroup owns whole groups: its four waves split a group's rows into four contiguous runs, keep column
+// sums in registers, and combine them through LDS in a fixed order -- no atomics, so the forward stays bit-reproducible.
+// group_rows is a multiple of R (a wave's step never straddles a group).
+template <typename T, int C, int POOL>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                           T* __restrict__ y, float* __restrict__ rinv_out,
+                                                                           int64_t ngroups, int d, int R, float eps, float drop_p,
+                                                                           uint64_t seed, float* __restrict__ pooled, int group_rows) {
+  __shared__ float red[4][C * 64 * 8];                 // per wave: the column sums of its C * 64 chunks
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nchunk = d >> 3;
+  const float inv_sqrt_d = rsqrtf((float)d);
+  int rsel[C], col[C];
+  f32x4 g0[C], g1[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = lane + 64 * c;
+    rsel[c] = k / nchunk;
+    col[c] = (k - rsel[c] * nchunk) * 8;
+    g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
+    g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+  }
+  const int steps = group_rows / R;                    // steps of R rows per group
+  const int per = (steps + 3) / 4;
+  const int s_lo = wave * per, s_hi = s_lo + per < steps ? s_lo + per : steps;
+  const float inv_group = 1.0f / (float)group_rows;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    float psum[C][8];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) psum[c][i] = 0.f;
+    for (int st = s_lo; st < s_hi; ++st) {
+      const int64_t row0 = g * group_rows + (int64_t)st * R;
+      const T* xr = x + row0 * d;
+      Vec8<T> v[C];
+      float ss[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c] = load8<T>(xr + (lane + 64 * c) * 8);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        ss[c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float f = v[c].get(i); ss[c] += f * f; }
+      }
+      float rr[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) rr[c] = 0.f;
+      for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += rsel[c] == r ? ss[c] : 0.f;
+        s = wave_sum(s);
+        const float rv = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+        if (lane == 0) rinv_out[row0 + r] = rv;
+#pragma unroll
+        for (int c = 0; c < C; ++c) rr[c] = rsel[c] == r ? rv : rr[c];
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)(row0 + rsel[c]) * d + col[c], km);
+        Vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.set(i, (i < 4 ? g0[c][i] : g1[c][i - 4]) * (v[c].get(i) * rr[c]) * km[i]);
+        if (POOL == 1) {
+          // the mean is taken over the values the literal path would have stored, i.e. after rounding to the activation type
+#pragma unroll
+          for (int i = 0; i < 8; ++i) psum[c][i] += o.get(i);
+        } else {
+          store8<T>(y + row0 * d + (lane + 64 * c) * 8, o);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) psum[c][i] += v[c].get(i);
+        }
+      }
+    }
+    // fixed-order combine: chunk k = lane + 64 c of wave w holds column (k mod nchunk) * 8 of row k / nchunk
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * c) * 8 + i] = psum[c][i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < R; ++r) s += red[w][r * d + j];
+      pooled[g * d + j] = s * inv_group;
+    }
+    __syncthreads();
+  }
+}
+
+// BC bit 0: dy is the gradient of the POOLED features, float [groups, d]: row r receives dy_g[r / group_rows] / group_rows
+// (the backward of POOL = 1 above -- no [tokens, d] broadcast is ever materialised); bit 1: the same for dres (POOL = 2).
+template <typename T, int C, int BC>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                            const float* __restrict__ scale,
                                                                            const float* __restrict__ rinv, T* __restrict__ dx,
                                                                            float* __restrict__ partial, int64_t rows, int d, int R,
                                                                            float eps, float drop_p, uint64_t seed,
-                                                                           const T* __restrict__ dres, const T* __restrict__ gelu_pre) {
+                                                                           const T* __restrict__ dres, const T* __restrict__ gelu_pre,
+                                                                           int group_rows) {
   __shared__ float red[MAXC * 512];                    // per-block gain-gradient columns (d <= 2048)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float inv_group = BC ? 1.0f / (float)group_rows : 0.f;
   const int nchunk = d >> 3;
   for (int j = threadIdx.x; j < d; j += NORM_THREADS) red[j] = 0.f;
   int rsel[C], col[C];
@@ -245,12 +344,16 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
     const int64_t row0 = grp * R;
     const int64_t off = row0 * d;
     Vec8<T> xv[C], dv[C], rv[C], pv[C];
+    Vec8<float> dvg[C], rvg[C];                        // broadcast (pooled) gradients, fp32
+    const int64_t pg = BC ? row0 / group_rows : 0;     // group of this step's rows (group_rows % R == 0)
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t o = off + (lane + 64 * c) * 8;
       xv[c] = load8<T>(x + o);
-      dv[c] = load8<T>(dy + o);
-      if (dres) rv[c] = load8<T>(dres + o);
+      if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
+      else dv[c] = load8<T>(dy + o);
+      if (BC & 2) rvg[c] = load8<float>(reinterpret_cast<const float*>(dres) + pg * d + col[c]);
+      else if (dres) rv[c] = load8<T>(dres + o);
       if (gelu_pre) pv[c] = load8<T>(gelu_pre + o);
     }
     float rr[C], cd[C], gd[C][8];
@@ -262,7 +365,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
       cd[c] = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float dyi = dv[c].get(i) * km[i];
+        const float dyi = ((BC & 1) ? dvg[c].get(i) * inv_group : dv[c].get(i)) * km[i];
         const float xi = xv[c].get(i);
         gacc[c][i] += dyi * xi * rr[c];
         const float t = (i < 4 ? g0[c][i] : g1[c][i - 4]) * dyi;
@@ -292,7 +395,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float val = rr[c] * gd[c][i] - kk[c] * xv[c].get(i);
-        if (dres) val += rv[c].get(i);
+        if (BC & 2) val += rvg[c].get(i) * inv_group;
+        else if (dres) val += rv[c].get(i);
         if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
         o.set(i, val);
       }
@@ -497,9 +601,9 @@ extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* sca
   if (R) {
     const int nbp = packed_blocks(rows / R);
 #define LAUNCH_BWD(CC)                                                                                                        \
-    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, 0>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
                                                 (const T*)dy, (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, R, eps,    \
-                                                drop_p, seed, (const T*)dres, (const T*)gelu_pre))
+                                                drop_p, seed, (const T*)dres, (const T*)gelu_pre, 1))
     if (C == 1) LAUNCH_BWD(1); else if (C == 2) LAUNCH_BWD(2); else LAUNCH_BWD(3);
 #undef LAUNCH_BWD
     MEANT_LAUNCH_CHECK("rmsnorm_bwd");
@@ -512,6 +616,61 @@ extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* sca
                                     (const T*)dres, (const T*)gelu_pre));
   MEANT_LAUNCH_CHECK("rmsnorm_bwd");
   return colsum_launch(workspace, d, dscale, nb, d, MEANT_F32, 0, (hipStream_t)stream);
+}
+
+// ---- pooled forms (the norms whose output or input feeds the sequence mean-pool only) ----
+extern "C" int meant_rmsnorm_pooled_ok(int64_t rows, int64_t d, int64_t group_rows) {
+  if (rows <= 0 || d <= 0 || d % 8 || d > MAXC * 512 || group_rows <= 0 || rows % group_rows) return 0;
+  int R, C;
+  norm_packing(rows, d, R, C);
+  return R != 0 && group_rows % R == 0;
+}
+
+extern "C" int meant_rmsnorm_fwd_pooled(const void* x, const float* scale, void* y, float* rinv, float* pooled, int64_t rows, int64_t d,
+                                        int64_t group_rows, int pool_input, float eps, float drop_p, uint64_t seed, int dtype,
+                                        void* stream) {
+  MEANT_REQUIRE(x && scale && rinv && pooled && (y || !pool_input), MEANT_ERR_ARG, "rmsnorm_fwd_pooled: null pointer");
+  MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows), MEANT_ERR_UNSUPPORTED,
+                "rmsnorm_fwd_pooled: rows=%lld d=%lld group_rows=%lld is not a packed shape (see meant_rmsnorm_pooled_ok)", (long long)rows,
+                (long long)d, (long long)group_rows);
+  MEANT_REQUIRE(meant_aligned16(x) && meant_aligned16(scale) && (!y || meant_aligned16(y)), MEANT_ERR_ARG, "rmsnorm_fwd_pooled: 16-byte alignment");
+  MEANT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MEANT_ERR_ARG, "rmsnorm_fwd_pooled: drop_p out of range");
+  int R, C;
+  norm_packing(rows, d, R, C);
+  const int64_t ngroups = rows / group_rows;
+  const int nb = (int)(ngroups < NORM_PACKED_BLOCKS ? ngroups : NORM_PACKED_BLOCKS);
+#define LAUNCH_FWDP(CC, PP)                                                                                                   \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_fwd_pooled_kernel<T, CC, PP>), dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+                                                (const T*)x, scale, (T*)y, rinv, ngroups, (int)d, R, eps, drop_p, seed, pooled, (int)group_rows))
+  if (pool_input) { if (C == 1) LAUNCH_FWDP(1, 2); else if (C == 2) LAUNCH_FWDP(2, 2); else LAUNCH_FWDP(3, 2); }
+  else { if (C == 1) LAUNCH_FWDP(1, 1); else if (C == 2) LAUNCH_FWDP(2, 1); else LAUNCH_FWDP(3, 1); }
+#undef LAUNCH_FWDP
+  MEANT_LAUNCH_CHECK("rmsnorm_fwd_pooled");
+  return MEANT_OK;
+}
+
+extern "C" int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv, void* dx,
+                                        float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps, float drop_p, uint64_t seed,
+                                        const void* dres, int dres_pooled, const void* gelu_pre, int dtype, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd_pooled: null pointer");
+  MEANT_REQUIRE((dy_pooled || dres_pooled) && (!dres_pooled || dres), MEANT_ERR_ARG, "rmsnorm_bwd_pooled: nothing pooled (use meant_rmsnorm_bwd)");
+  MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows), MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_pooled: not a packed shape");
+  MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_pooled: workspace too small");
+  int R, C;
+  norm_packing(rows, d, R, C);
+  const int nbp = packed_blocks(rows / R);
+  const int bc = (dy_pooled ? 1 : 0) | (dres_pooled ? 2 : 0);
+#define LAUNCH_BWDP(CC, BB)                                                                                                   \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, BB>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+                                                (const T*)dy, (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, R, eps,    \
+                                                drop_p, seed, (const T*)dres, (const T*)gelu_pre, (int)group_rows))
+#define LAUNCH_BWDP_C(BB) { if (C == 1) LAUNCH_BWDP(1, BB); else if (C == 2) LAUNCH_BWDP(2, BB); else LAUNCH_BWDP(3, BB); }
+  if (bc == 1) LAUNCH_BWDP_C(1) else if (bc == 2) LAUNCH_BWDP_C(2) else LAUNCH_BWDP_C(3)
+#undef LAUNCH_BWDP_C
+#undef LAUNCH_BWDP
+  MEANT_LAUNCH_CHECK("rmsnorm_bwd_pooled");
+  return colsum_launch(workspace, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
 }
 
 extern "C" int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,

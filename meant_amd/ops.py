@@ -270,6 +270,90 @@ def linear_gelu_rmsnorm(x, weight, bias, scale, eps=1e-8, drop_p=0.0, seed=0):
     return _GeluRMSNorm.apply(a, pre, scale, float(eps), float(drop_p), int(seed))
 
 
+# ---- pooled forms: the norms next to the sequence mean-pool (see _PooledLinearCat below) -------------------------------
+def pooled_norm_ok(x, group_rows: int) -> bool:
+    d = x.shape[-1]
+    return bool(lib.meant_rmsnorm_pooled_ok(x.numel() // d, d, int(group_rows)))
+
+
+def _rmsnorm_bwd_pooled_raw(dy, dy_pooled, x, sc, rinv, S, eps, drop_p, seed, dres, dres_pooled, gelu_pre):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dscale = torch.empty(d, device=x.device, dtype=torch.float32)
+    wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+    check(lib.meant_rmsnorm_bwd_pooled(_p(dy), int(dy_pooled), _p(x), _p(sc), _p(rinv), _p(dx), _p(dscale), rows, d, S, eps, drop_p, seed,
+                                       _p(dres), int(dres_pooled), _p(gelu_pre), _dt(x), _p(ws), wsb, _stream()), "rmsnorm_bwd_pooled")
+    return dx, dscale
+
+
+class _RMSNormForkPooled(torch.autograd.Function):
+    """(RMSNorm(x), mean over each sequence of x): the second output replaces the residual operand x of _RMSNormFork when the
+    only thing the residual feeds is the mean-pool.  x [G, S, d]; the mean is float [G, d] and comes out of the norm's own
+    pass over x; its gradient is added row-wise inside the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, scale, eps):
+        _need_gpu(x, scale)
+        x = _c(x)
+        G, S, d = x.shape
+        y = torch.empty_like(x)
+        rinv = torch.empty(G * S, device=x.device, dtype=torch.float32)
+        xm = torch.empty((G, d), device=x.device, dtype=torch.float32)
+        sc = _c(scale.detach().float())
+        check(lib.meant_rmsnorm_fwd_pooled(_p(x), _p(sc), _p(y), _p(rinv), _p(xm), G * S, d, S, 1, eps, 0.0, 0, _dt(x), _stream()),
+              "rmsnorm_fwd_pooled")
+        ctx.save_for_backward(x, sc, rinv)
+        ctx.eps, ctx.S = eps, S
+        return y, xm
+
+    @staticmethod
+    def backward(ctx, dy, dxm):
+        x, sc, rinv = ctx.saved_tensors
+        if dxm is None:
+            dx, dscale = _rmsnorm_bwd_raw(_c(dy), x, sc, rinv, ctx.eps, 0.0, 0)
+        else:
+            dx, dscale = _rmsnorm_bwd_pooled_raw(_c(dy), False, x, sc, rinv, ctx.S, ctx.eps, 0.0, 0, _c(dxm.float()), True, None)
+        return dx, dscale, None
+
+
+class _GeluRMSNormPooled(torch.autograd.Function):
+    """mean over each sequence of dropout(RMSNorm(gelu(pre))) given a = gelu(pre) and pre (see _GeluRMSNorm): float [G, d].
+    The normalised tokens themselves are never written, and the backward reads the [G, d] gradient of the mean."""
+
+    @staticmethod
+    def forward(ctx, a, pre, scale, eps, drop_p, seed):
+        _need_gpu(a, pre, scale)
+        a = _c(a)
+        G, S, d = a.shape
+        rinv = torch.empty(G * S, device=a.device, dtype=torch.float32)
+        hm = torch.empty((G, d), device=a.device, dtype=torch.float32)
+        sc = _c(scale.detach().float())
+        check(lib.meant_rmsnorm_fwd_pooled(_p(a), _p(sc), None, _p(rinv), _p(hm), G * S, d, S, 0, eps, drop_p, seed, _dt(a), _stream()),
+              "rmsnorm_fwd_pooled")
+        ctx.save_for_backward(a, _c(pre), sc, rinv)
+        ctx.args, ctx.S = (eps, drop_p, seed), S
+        return hm
+
+    @staticmethod
+    def backward(ctx, dhm):
+        a, pre, sc, rinv = ctx.saved_tensors
+        eps, drop_p, seed = ctx.args
+        dpre, dscale = _rmsnorm_bwd_pooled_raw(_c(dhm.float()), True, a, sc, rinv, ctx.S, eps, drop_p, seed, None, False, pre)
+        return None, dpre, dscale, None, None, None
+
+
+def rmsnorm_fork_pooled(x, scale, eps=1e-8):
+    return _RMSNormForkPooled.apply(x, scale, float(eps))
+
+
+def linear_gelu_rmsnorm_pooled(x, weight, bias, scale, eps=1e-8, drop_p=0.0, seed=0):
+    """mean_s(dropout(RMSNorm(gelu(x W^T + b)))) -> float [G, d]"""
+    a, pre = _LinearPre.apply(x, weight, bias)
+    return _GeluRMSNormPooled.apply(a, pre, scale, float(eps), float(drop_p), int(seed))
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -630,6 +714,11 @@ def meanpool_cat(a, b=None):
     return _MeanPoolCat.apply(a, b, torch.float32 if TAIL_FP32 else a.dtype)
 
 
+def meanpool_f32(a):
+    """mean over the sequence axis of [G, S, d] -> float [G, d]"""
+    return _MeanPoolCat.apply(a, None, torch.float32)
+
+
 class _PoolLinearCat(torch.autograd.Function):
     """torch.cat([mean_s(h_a W_a^T + b_a + x_a), mean_n(h_b W_b^T + b_b + x_b)], -1): the LAST Linear (+ residual) of the last
     encoder layer of each stack followed by the sequence mean-pool (meant/meant.py:74 / :120 -> :231), evaluated as
@@ -691,11 +780,64 @@ class _PoolLinearCat(torch.autograd.Function):
         return tuple(grads)
 
 
+class _PooledLinearCat(torch.autograd.Function):
+    """as _PoolLinearCat, on means that the norm kernels already produced: parts (hm [G, d] float, xm [G, d] float, W, b)"""
+
+    @staticmethod
+    def forward(ctx, out_dtype, *flat):
+        parts = [flat[i:i + 4] for i in range(0, len(flat), 4)]
+        _need_gpu(*[t for p in parts for t in p])
+        G = parts[0][0].shape[0]
+        widths = [p[2].shape[0] for p in parts]
+        Dt = sum(widths)
+        dev = parts[0][0].device
+        out = torch.empty((G, Dt), device=dev, dtype=torch.float32)
+        # the generic fp32 GEMM wants residual stride == output stride: the means of x side by side, like `out`
+        xs = _c(parts[0][1]) if len(parts) == 1 else torch.cat([p[1] for p in parts], dim=1)
+        saved, off = [], 0
+        for (hm, xm, W, b), N in zip(parts, widths):
+            hm = _c(hm)
+            K = hm.shape[1]
+            w_f = _c(W.detach().float())
+            bias_f = _c(b.detach().float()) if b is not None else None
+            check(lib.meant_linear_fwd(_p(hm), K, _p(w_f), _p(bias_f), xs.data_ptr() + off * 4, Dt, out.data_ptr() + off * 4, Dt, None,
+                                       G, N, K, EPI_RESIDUAL, F32, _stream()), "linear_fwd")
+            saved.append((hm, W, b is not None, off))
+            off += N
+        ctx.parts = saved
+        return cast(out, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = cast(_c(dout), torch.float32)
+        G, Dt = dout.shape
+        grads = [None]
+        for hm, W, has_b, off in ctx.parts:
+            N, K = W.shape
+            dy_ptr = dout.data_ptr() + off * 4
+            wT = weights.get((W,), torch.float32, True)
+            dhm = torch.empty((G, K), device=dout.device, dtype=torch.float32)
+            check(lib.meant_linear_bwd_dx(dy_ptr, Dt, _p(wT), _p(dhm), K, G, N, K, F32, _stream()), "linear_bwd_dx")
+            dw = torch.zeros((N, K), device=dout.device, dtype=torch.float32)
+            db = torch.zeros(N, device=dout.device, dtype=torch.float32) if has_b else None
+            check(lib.meant_linear_bwd_dw(dy_ptr, Dt, _p(hm), K, _p(dw), _p(db), G, N, K, F32, None, 0, _stream()), "linear_bwd_dw")
+            dxm = dout[:, off:off + N] if Dt == N else dout[:, off:off + N].contiguous()
+            grads += [dhm, dxm, dw, db]
+        return tuple(grads)
+
+
 def pool_linear_cat(parts):
     """parts: [(h, x, weight, bias), ...] (one or two): cat_p(mean_tokens(h_p W_p^T + b_p + x_p)) -> [G, sum d_p]"""
-    out_dtype = torch.float32 if TAIL_FP32 else parts[0][0].dtype
     flat = [t for p in parts for t in p]
+    out_dtype = torch.float32 if TAIL_FP32 else parts[0][0].dtype
     return _PoolLinearCat.apply(out_dtype, *flat)
+
+
+def pooled_linear_cat(parts, compute_dtype):
+    """parts: [(mean_s(h) [G, d] float, mean_s(x) [G, d] float, weight, bias), ...] -> cat_p(hm_p W_p^T + b_p + xm_p) in the dtype
+    of everything after the pooling"""
+    out_dtype = torch.float32 if TAIL_FP32 else compute_dtype
+    return _PooledLinearCat.apply(out_dtype, *[t for p in parts for t in p])
 
 
 class _AddRowVec(torch.autograd.Function):

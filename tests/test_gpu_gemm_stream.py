@@ -89,14 +89,19 @@ def test_streaming_linear(L, dev, M_, N, K, epi, dynamic):
 
 
 @pytest.mark.parametrize("epi", ["none", "residual", "gelu"])
-def test_streaming_linear_few_workgroups_steals(L, dev, epi):
-    """64 workgroups (8 per XCD) for 432 tiles: ~7 tiles per workgroup, XCDs 6 and 7 own one round less than the others and
-    run dry first -> the steal path (gemm_bf16.hip, 'this XCD is dry') delivers real tiles."""
-    before = L.lib.meant_debug_nt_steals()
+def test_streaming_linear_few_workgroups_and_steals(L, dev, epi):
+    """64 workgroups (8 per XCD) on 432 tiles: ~7 tiles per workgroup through the dynamic draw; then the same with
+    nt_dynamic = 3, where only XCD 0 draws from its own counter and the tiles of the other seven counters can only be
+    handed out by the steal path (gemm_bf16.hip, 'this XCD is dry'): the counter of stolen tiles must move, and the values
+    are checked against the oracle in both runs."""
     r = _linear_case(L, dev, 36864, 768, 768, epi, 1, 64)
     assert r["nt256s"] == 1
-    after = L.lib.meant_debug_nt_steals()
-    assert after > before, "no tile changed XCD: the steal path did not run"
+    before = L.lib.meant_debug_nt_steals()
+    r = _linear_case(L, dev, 36864, 768, 768, epi, 3, 64)
+    assert r["nt256s"] == 1
+    stolen = L.lib.meant_debug_nt_steals() - before
+    # forward and dX: 2 x (432 tiles - 64 first tiles - XCD 0's own share of the rest)
+    assert stolen >= 2 * (432 - 64) * 3 // 4, f"only {stolen} tiles went through the steal path"
 
 
 @pytest.mark.parametrize("dynamic", [1, 0], ids=["dyn", "fixed"])
