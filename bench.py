@@ -253,7 +253,7 @@ def main():
     if world > 1:                                   # identical replicas: broadcast rank 0's weights once
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-    reducer = GradReducer(model.parameters(), bucket_mb=64.0)
+    reducer = GradReducer(model.parameters(), bucket_mb=64.0, direct_grads=True)
     tweets, images, mask, target = make_batch(B, rank, dev)
 
     def step():

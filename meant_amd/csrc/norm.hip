@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
     const int64_t off = row0 * d;
     Vec8<T> xv[C], dv[C], rv[C], pv[C];
     Vec8<float> dvg[C], rvg[C];                        // broadcast (pooled) gradients, fp32
-    const int64_t pg = BC ? row0 / group_rows : 0;     // group of this step's rows (group_rows % R == 0)
+    const int64_t pg = BC ? (int64_t)((unsigned)row0 / (unsigned)group_rows) : 0;   // group of this step's rows (32-bit divide: rows < 2^31 is checked)
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t o = off + (lane + 64 * c) * 8;
@@ -655,7 +655,7 @@ extern "C" int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const voi
                                         size_t workspace_bytes, void* stream) {
   MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd_pooled: null pointer");
   MEANT_REQUIRE((dy_pooled || dres_pooled) && (!dres_pooled || dres), MEANT_ERR_ARG, "rmsnorm_bwd_pooled: nothing pooled (use meant_rmsnorm_bwd)");
-  MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows), MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_pooled: not a packed shape");
+  MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows) && rows < 2147483647LL, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_pooled: not a packed shape");
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_pooled: workspace too small");
   int R, C;
   norm_packing(rows, d, R, C);

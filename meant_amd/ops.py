@@ -245,7 +245,7 @@ class _LinearPre(torch.autograd.Function):
         w_c = weights.get((weight,), x.dtype, False)
         bias_f = _c(bias.detach().float()) if bias is not None else None
         y, pre = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_GELU, True)
-        ctx.weight, ctx.has_bias, ctx.in_shape = weight, bias is not None, shp
+        ctx.weight, ctx.bias, ctx.has_bias, ctx.in_shape = weight, bias, bias is not None, shp
         ctx.save_for_backward(x2)
         N = weight.shape[0]
         yv, pv = y.view(*shp[:-1], N), pre.view(*shp[:-1], N)
@@ -260,7 +260,7 @@ class _LinearPre(torch.autograd.Function):
         (x2,) = ctx.saved_tensors
         N = ctx.weight.shape[0]
         d2 = _c(dpre).view(-1, N)
-        dx, dw, db = _linear_bwd_raw(d2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias)
+        dx, dw, db = _linear_bwd_raw(d2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias, bias_param=ctx.bias)
         return (dx.view(ctx.in_shape) if dx is not None else None), dw, db
 
 
@@ -411,8 +411,25 @@ def _bwd_dw(dy2, x2, dw, db):
           "linear_bwd_dw")
 
 
-def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0):
-    """returns dx2 (or None), dW [sum N_i (+ pad_rows), K] fp32, db [same] fp32 or None"""
+# Gradient sinks: a gradient reducer (meant_amd.parallel.GradReducer(direct_grads=True)) registers, per parameter, the
+# view of its flat bucket that IS the parameter's .grad and a callback.  A Linear whose weight (and bias) have a sink
+# accumulates dW / db straight into those views -- the C ABI's contract is "+=" -- and reports to the callback, instead of
+# handing autograd a freshly zeroed tensor that AccumulateGrad then adds to the same view with one more launch each
+# (~100 small fills and adds per step).  Valid for parameters that one autograd node produces per backward; the reducer
+# raises if a parameter reports twice.
+grad_sinks = {}
+
+
+def _sink_of(param):
+    ent = grad_sinks.get(id(param))
+    if ent is None or ent[0]() is not param:
+        return None
+    return ent
+
+
+def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0, bias_param=None):
+    """returns dx2 (or None), dW [sum N_i (+ pad_rows), K] fp32, db [same] fp32 or None; dW / db are None when they went
+    straight into the parameters' gradient sinks"""
     M, N = dy2.shape
     K = x2.shape[1]
     dx = None
@@ -420,6 +437,14 @@ def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0):
         wT = weights.get(params, dy2.dtype, True, pad_rows)             # [K, N]
         dx = torch.empty((M, K), device=dy2.device, dtype=dy2.dtype)
         check(lib.meant_linear_bwd_dx(_p(dy2), dy2.stride(0), _p(wT), _p(dx), K, M, N, K, _dt(dy2), _stream()), "linear_bwd_dx")
+    if len(params) == 1 and pad_rows == 0 and grad_sinks:
+        ws_, bs_ = _sink_of(params[0]), (_sink_of(bias_param) if has_bias else None)
+        if ws_ is not None and (not has_bias or bs_ is not None) and ws_[1].shape == (N, K) and ws_[1].is_contiguous():
+            _bwd_dw(dy2, x2, ws_[1], bs_[1] if has_bias else None)
+            ws_[2](params[0])
+            if has_bias:
+                bs_[2](bias_param)
+            return dx, None, None
     dw = torch.zeros((N, K), device=dy2.device, dtype=torch.float32)
     db = torch.zeros(N, device=dy2.device, dtype=torch.float32) if has_bias else None
     _bwd_dw(dy2, x2, dw, db)
@@ -442,7 +467,7 @@ class _Linear(torch.autograd.Function):
         ctx.epilogue = epilogue
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
-        ctx.weight = weight
+        ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x2, pre if (epilogue & EPI_GELU) else (y if (epilogue & EPI_SIGMOID) else None))
         ctx.in_shape = shp
         return y.view(*shp[:-1], weight.shape[0])
@@ -461,7 +486,7 @@ class _Linear(torch.autograd.Function):
             d2 = torch.empty_like(dy2)
             check(lib.meant_sigmoid_bwd(_p(dy2), _p(aux), _p(d2), dy2.numel(), _dt(dy2), _stream()), "sigmoid_bwd")
             dy2 = d2
-        dx, dw, db = _linear_bwd_raw(dy2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias)
+        dx, dw, db = _linear_bwd_raw(dy2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias, bias_param=ctx.bias)
         return (dx.view(ctx.in_shape) if dx is not None else None), dw, db, dres, None
 
 

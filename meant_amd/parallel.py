@@ -41,7 +41,11 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None,
-                 average: bool = True):
+                 average: bool = True, direct_grads: bool = False):
+        """direct_grads: let the Linear backward write dW / db straight into the bucket views (meant_amd.ops.grad_sinks)
+        instead of returning fresh tensors for autograd to add to them.  Requires every such parameter to be used by one
+        autograd node per backward pass (true for the MEANT models: no weight sharing between Linears); a parameter that
+        reports twice in one step raises."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -89,11 +93,26 @@ class GradReducer:
             for p in b.params:
                 self._owner[id(p)] = b
                 p.register_post_accumulate_grad_hook(self._hook)
+        self.direct_grads = direct_grads
+        self._reported = set()
         self.prepare()
+        if direct_grads:
+            self._register_sinks()
+
+    def _register_sinks(self):
+        import weakref
+        from . import ops
+        for b in self.buckets:
+            for p, off in zip(b.params, b.offsets):
+                if p.is_cuda:
+                    view = b.flat[off:off + p.numel()].view_as(p)
+                    ops.grad_sinks[id(p)] = (weakref.ref(p), view, self._sink_report)
+                    weakref.finalize(p, ops.grad_sinks.pop, id(p), None)
 
     # -- per step ---------------------------------------------------------------------------
     def prepare(self):
         """zero the buckets (== zero_grad) and re-arm the hooks; call before each backward"""
+        self._reported.clear()
         for b in self.buckets:
             b.flat.zero_()
             b.pending = len(b.params)
@@ -104,7 +123,21 @@ class GradReducer:
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * 4:
                     p.grad = b.flat[off:off + n].view_as(p)
 
+    def _sink_report(self, p):
+        """called by a backward that accumulated this parameter's gradient straight into its bucket view"""
+        if id(p) in self._reported:
+            raise RuntimeError(f"GradReducer(direct_grads=True): a parameter of shape {tuple(p.shape)} received its gradient twice "
+                               "in one backward pass (shared weights?); construct the reducer with direct_grads=False")
+        self._reported.add(id(p))
+        self._count(p)
+
     def _hook(self, p):
+        """autograd's post-accumulate hook; a parameter whose gradient went through its sink has been counted already"""
+        if id(p) in self._reported:
+            return
+        self._count(p)
+
+    def _count(self, p):
         b = self._owner[id(p)]
         b.pending -= 1
         if p.is_cuda:

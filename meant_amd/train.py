@@ -138,7 +138,7 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-5, weight_decay: float = 1e-2, max_grad_norm: float = 1.0,
                  bucket_mb: float = 64.0):
         self.model = model
-        self.reducer = GradReducer(model.parameters(), bucket_mb=bucket_mb)
+        self.reducer = GradReducer(model.parameters(), bucket_mb=bucket_mb, direct_grads=True)
         self.opt = FusedAdamW(self.reducer, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
 
     def __call__(self, *inputs, target):
