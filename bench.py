@@ -14,10 +14,15 @@ gradient all-reduce overlapped with backward.  No optimizer step (the metric is 
 Weak scaling: 128 samples per GPU (global batch 1024 at 8 GPUs, BASELINE.json configs[3]).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (gemm_bf16_nt256s_kernel, MFMA-bound): algorithmic FLOPs of its launches
-                  / their HIP-event durations, measured live inside the timed steps;
-  cpu_baseline -- the CPU oracle (a port: the reference is Python and cannot travel) timed on the host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline     -- the dominant kernel (gemm_bf16_nt256s_kernel, MFMA-bound): algorithmic FLOPs of its launches / their
+                  HIP-event durations.  The timed steps run the two encoder stacks on two HIP streams, where a launch
+                  shares the CUs with the other stream's kernels and has no duration of its own; the events are
+                  therefore taken in `roofline.timed_in` extra single-stream steps right after the timed region (the
+                  figure measured inside it is reported beside it).  `roofline.others` carries the same for the
+                  other hot kernels: dW GEMM and attention against the MFMA peak, RMSNorm / attention against HBM;
+  cpu_baseline -- the CPU oracle (a port: the reference is Python and cannot travel) timed on the host cores on a bounded
+                  sample of the same workload (rank 0, N=1 only): batch 1 and batch 8 on all the box's threads, batch 1
+                  on one thread.
 """
 from __future__ import annotations
 
@@ -35,6 +40,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16 peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md (~8 TB/s; ~6.3 TB/s is what a streaming kernel reaches)
 V, D, H, L, S, IMG, P, C, NCLS = 64001, 768, 12, 12, 512, 224, 16, 4, 2
 
 
@@ -65,24 +71,29 @@ class GemmTimer:
 
     def __init__(self):
         self.recs = []
+        self.other = []          # (kind, e0, e1, flops, bytes) of the other hot kernels
         self.enabled = False
+        self.others_enabled = False     # the other kernels are timed in the single-stream steps only
 
     def install(self):
         from meant_amd import ops
         lib = ops.lib
         timer = self
 
-        def wrap(name, flops_of, key_of):
+        def wrap(name, flops_of, key_of, kind="nt", bytes_of=None):
             orig = getattr(lib, name)
 
             def call(*a):
-                if not timer.enabled:
+                if not timer.enabled or (kind != "nt" and not timer.others_enabled):
                     return orig(*a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = orig(*a)
                 e1.record()
-                timer.recs.append((e0, e1, flops_of(a), key_of(a)))
+                if kind == "nt":
+                    timer.recs.append((e0, e1, flops_of(a), key_of(a)))
+                else:
+                    timer.other.append((kind, e0, e1, flops_of(a) if flops_of else 0.0, bytes_of(a) if bytes_of else 0.0))
                 return rc
             return call
 
@@ -105,7 +116,51 @@ class GemmTimer:
         # meant_qkv_proj_fwd(x, ldx, w, bias, qkv, M, K, S, H, Dh, R, qa, qb, ka, kb, dtype, stream)
         proxy.meant_qkv_proj_fwd = wrap("meant_qkv_proj_fwd", lambda a: nt256(a[5], 3 * a[8] * a[9], a[6], a[15]),
                                         lambda a: (a[5], 3 * a[8] * a[9], a[6], 0.0))
+        # the other hot kernels, with their algorithmic work: FLOPs (2 m n k; attention full-square:
+        # 4 S^2 Dh per (group, head) forward, 2.5 x that backward) and / or HBM bytes (every operand once)
+        es = 2.0                                                                   # bf16 activations
+        # meant_linear_bwd_dw(dy, lddy, x, ldx, dw, db, M, N, K, dtype, ws, wsb, stream)
+        proxy.meant_linear_bwd_dw = wrap("meant_linear_bwd_dw", lambda a: 2.0 * a[6] * a[7] * a[8] if (a[9] == 1 and a[6] >= 4096 and a[7] % 256 == 0 and a[8] % 256 == 0) else 0.0,
+                                         None, "dw_gemm (gemm_bf16_tn256_kernel)")
+        # meant_attn_fwd(qkv, o, lse, km, G, S, H, Dh, scale, causal, dtype, ws, wsb, stream)
+        proxy.meant_attn_fwd = wrap("meant_attn_fwd", lambda a: 4.0 * a[4] * a[6] * a[5] * a[5] * a[7], None, "attn_fwd",
+                                    lambda a: 4.0 * a[4] * a[5] * a[6] * a[7] * es)
+        # meant_attn_bwd(qkv, o, do, lse, km, dqkv, G, S, H, Dh, ...)
+        proxy.meant_attn_bwd = wrap("meant_attn_bwd", lambda a: 10.0 * a[6] * a[8] * a[7] * a[7] * a[9], None, "attn_bwd (dq + dkv)",
+                                    lambda a: 9.0 * a[6] * a[7] * a[8] * a[9] * es)
+        # meant_rmsnorm_fwd(x, scale, y, rinv, rows, d, ...): read x, write y
+        proxy.meant_rmsnorm_fwd = wrap("meant_rmsnorm_fwd", None, None, "rmsnorm_fwd", lambda a: 2.0 * a[4] * a[5] * es)
+        # meant_rmsnorm_fwd_pooled(x, scale, y, rinv, pooled, rows, d, group_rows, pool_input, ...): read x (+ write y when pool_input)
+        proxy.meant_rmsnorm_fwd_pooled = wrap("meant_rmsnorm_fwd_pooled", None, None, "rmsnorm_fwd_pooled",
+                                              lambda a: (2.0 if a[8] else 1.0) * a[5] * a[6] * es)
+        # meant_rmsnorm_bwd(dy, x, scale, rinv, dx, dscale, rows, d, eps, p, seed, dres, gelu_pre, ...): read dy, x (+ dres, gelu_pre), write dx
+        proxy.meant_rmsnorm_bwd = wrap("meant_rmsnorm_bwd", None, None, "rmsnorm_bwd",
+                                       lambda a: (3.0 + (1 if a[11] else 0) + (1 if a[12] else 0)) * a[6] * a[7] * es)
+        # meant_rmsnorm_bwd_pooled(dy, dy_pooled, x, scale, rinv, dx, dscale, rows, d, group_rows, eps, p, seed, dres, dres_pooled, gelu_pre, ...)
+        proxy.meant_rmsnorm_bwd_pooled = wrap("meant_rmsnorm_bwd_pooled", None, None, "rmsnorm_bwd_pooled",
+                                              lambda a: (2.0 + (0 if a[1] else 1) + (1 if (a[13] and not a[14]) else 0) + (1 if a[15] else 0)) * a[7] * a[8] * es)
         ops.lib = proxy
+
+    def others_summary(self):
+        """per kind: launches, mean ms, achieved TFLOP/s and GB/s of the algorithmic work, fractions of the peaks"""
+        agg = {}
+        for kind, e0, e1, f, b in self.other:
+            if f <= 0 and b <= 0:
+                continue
+            t = e0.elapsed_time(e1) * 1e-3
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += t; a[2] += f; a[3] += b
+        out = {}
+        for kind, (n, t, f, b) in agg.items():
+            ent = {"launches": n, "avg_ms": round(t / n * 1e3, 4)}
+            if f > 0:
+                ent["tflops"] = round(f / t / 1e12, 1)
+                ent["mfma_frac"] = round(f / t / 1e12 / PEAK_BF16_TFLOPS, 4)
+            if b > 0:
+                ent["gb_per_s"] = round(b / t / 1e9, 1)
+                ent["hbm_frac"] = round(b / t / 1e9 / PEAK_HBM_GBS, 4)
+            out[kind] = ent
+        return out
 
     def summary(self, recs=None):
         tot_t, tot_f, n = 0.0, 0.0, 0
@@ -162,35 +217,40 @@ def make_batch(B: int, rank: int, device):
     return tweets, images, mask.to(device), target
 
 
-def cpu_baseline(E: int, seconds_budget: float = 25.0):
-    """the oracle on the host cores: C3 config, B=1, fp32 eager, eval mode, fwd + CE + bwd"""
+def cpu_baseline(E: int):
+    """the oracle on the host cores: C3 config, fp32 eager, eval mode, fwd + CE + bwd.  SURVEY 8(d): batch 1 and batch 8
+    on the box's threads (16 for a 1-GPU box), and batch 1 on a single thread.  Bounded: ~30 s in all."""
     from oracle import meant_oracle as O
     torch.manual_seed(0)
     cores = min(os.cpu_count() or 1, 16)            # the 1-GPU box gives a 16-thread CPU share
-    torch.set_num_threads(cores)
     m = O.meant(D, D, 4, IMG, IMG, P, L, NCLS, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C).eval()
     O.fill_weights_(m, 1234)
     rs = np.random.RandomState(99)
-    ids = torch.from_numpy(rs.randint(0, V, (1, L, S)).astype("int64"))
-    img = torch.from_numpy(rs.standard_normal((1, L, C, IMG, IMG)).astype("float32"))
-    mask = torch.ones(1, L, S)
-    mask[0, :, 400:] = 0
-    tgt = torch.tensor([1])
-    times = []
-    t_start = time.time()
-    for it in range(7):
-        t0 = time.time()
-        m.zero_grad(set_to_none=True)
-        O.cross_entropy_on_probs(m(ids, img, mask), tgt).backward()
-        dt = time.time() - t0
-        if it >= 2:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and len(times) >= 2:
-            break
-    med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "samples/s", "cores": int(cores), "kind": "port",
+
+    def run(B, threads, warm, reps):
+        torch.set_num_threads(threads)
+        ids = torch.from_numpy(rs.randint(0, V, (B, L, S)).astype("int64"))
+        img = torch.from_numpy(rs.standard_normal((B, L, C, IMG, IMG)).astype("float32"))
+        mask = torch.ones(B, L, S)
+        mask[:, :, 400:] = 0
+        tgt = torch.from_numpy(rs.randint(0, NCLS, (B,)).astype("int64"))
+        times = []
+        for it in range(warm + reps):
+            t0 = time.time()
+            m.zero_grad(set_to_none=True)
+            O.cross_entropy_on_probs(m(ids, img, mask), tgt).backward()
+            if it >= warm:
+                times.append(time.time() - t0)
+        return B / float(np.median(times)), len(times)
+
+    v1, n1 = run(1, cores, 2, 5)
+    v8, n8 = run(8, cores, 1, 2)
+    vs, ns = run(1, 1, 1, 2)
+    return {"value": round(v1, 4), "unit": "samples/s", "cores": int(cores), "kind": "port",
             "sample": f"CPU oracle (fp32 eager restatement pinned to the reference's golden vectors), same MEANT config "
-                      f"(lag=12, d=768, S=512, 224x224, E={E}), batch 1, fwd+CE+bwd, median of {len(times)} iterations after 2 warm-ups"}
+                      f"(lag=12, d=768, S=512, 224x224, E={E}), batch 1, fwd+CE+bwd, median of {n1} iterations after 2 warm-ups",
+            "batch8": {"value": round(v8, 4), "cores": int(cores), "sample": f"same, batch 8, median of {n8} after 1 warm-up"},
+            "single_thread": {"value": round(vs, 4), "cores": 1, "sample": f"same, batch 1 on one thread, median of {ns} after 1 warm-up"}}
 
 
 def main():
@@ -285,15 +345,15 @@ def main():
     import meant_amd.modules as _mm
     overlapped_recs, iso_steps = timer.recs, 0
     if _mm.TWO_STREAMS:                             # every rank: the step holds the gradient collective
-        timer.recs, iso_steps = [], min(args.steps, 4)
+        timer.recs, timer.other, iso_steps = [], [], min(args.steps, 4)
         _mm.TWO_STREAMS = False
         step()
         torch.cuda.synchronize()
-        timer.enabled = True
+        timer.enabled = timer.others_enabled = True
         for _ in range(iso_steps):
             step()
         torch.cuda.synchronize()
-        timer.enabled = False
+        timer.enabled = timer.others_enabled = False
         _mm.TWO_STREAMS = True
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -387,6 +447,7 @@ def main():
             n2, gf2, gt2 = timer.summary(overlapped_recs)
             roofline["timed_in"] = f"{iso_steps} extra single-stream steps after the timed region"
             roofline["achieved_while_sharing_cus_with_second_stream"] = round(gf2 / gt2 / 1e12, 1) if gt2 > 0 else None
+        roofline["others"] = timer.others_summary()
         res = {"metric": "samples/sec fwd+bwd, MEANT lag=12 d=768", "value": round(sps, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
