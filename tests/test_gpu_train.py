@@ -154,3 +154,75 @@ def test_grad_reducer_over_rccl_one_rank(dev):
                MEANT_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_TWO_RANKS_ON_ONE_GPU = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MEANT_REPO"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share GPU 0: RCCL needs one device per rank
+torch.cuda.set_device(0)
+import numpy as np
+import meant_amd
+from meant_amd.parallel import GradReducer, shard_batch
+from meant_amd.train import cross_entropy_on_probs
+torch.manual_seed(0)
+model = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=2).cuda().eval()
+model.compute_dtype = torch.bfloat16
+d = torch.load(os.environ["MEANT_BATCH"])
+lo, hi = shard_batch(d["ids"].shape[0], rank, world)
+red = GradReducer(model.parameters(), bucket_mb=0.25, direct_grads=True)
+assert red.active and red.num_buckets > 1 and not red.fused_avg
+for _ in range(2):                                                # two steps: prepare() re-arms the hooks and the sinks
+    red.prepare()
+    out = model(d["ids"][lo:hi].cuda(), d["img"][lo:hi].cuda(), d["mask"][lo:hi].cuda())
+    cross_entropy_on_probs(out, d["tgt"][lo:hi].cuda()).backward()
+    assert any(b.handle is not None for b in red.buckets), "no collective was launched during backward"
+    red.wait()
+torch.cuda.synchronize()
+if rank == 0:
+    torch.save({k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}, os.environ["MEANT_OUT"])
+dist.barrier()
+dist.destroy_process_group()
+print("TWO_RANKS_OK", rank)
+"""
+
+
+def test_two_ranks_share_one_gpu_reduced_grads_equal_single_process(dev, tmp_path):
+    """bench.py's N > 1 path rehearsed on one GPU: two processes, one rank each, both on cuda:0 over gloo, the HIP modules,
+    the batch sharded by shard_batch, gradients written straight into the reducer's buckets (direct_grads) and all-reduced
+    from the autograd hooks while backward runs.  The averaged gradients must equal those of ONE process on the whole
+    batch (mean loss over equal shards == mean over the batch), which is what the 8-GPU launch relies on."""
+    import os
+    import subprocess
+    import sys
+    import meant_amd
+    from meant_amd.train import cross_entropy_on_probs
+    rs = np.random.RandomState(17)
+    batch = {"ids": torch.from_numpy(rs.randint(0, 100, (4, 3, 16))), "img": torch.from_numpy(rs.standard_normal((4, 3, 4, 32, 32)).astype("float32")),
+             "mask": torch.ones(4, 3, 16), "tgt": torch.tensor([0, 1, 1, 0])}
+    batch["mask"][1, :, 9:] = 0
+    bpath, opath = str(tmp_path / "batch.pt"), str(tmp_path / "grads.pt")
+    torch.save(batch, bpath)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
+                   MEANT_REPO=root, MEANT_BATCH=bpath, MEANT_OUT=opath, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANKS_ON_ONE_GPU], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "TWO_RANKS_OK" in so, so[-2000:] + se[-4000:]
+    got = torch.load(opath)
+    torch.manual_seed(0)
+    model = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=2).to(dev).eval()
+    model.compute_dtype = torch.bfloat16
+    out = model(batch["ids"].to(dev), batch["img"].to(dev), batch["mask"].to(dev))
+    cross_entropy_on_probs(out, batch["tgt"].to(dev)).backward()
+    assert set(got) == {k for k, p in model.named_parameters() if p.grad is not None}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        ref = p.grad.detach().float().cpu()
+        # bf16 tier: the two half-batches round differently from the whole batch only in the last bits of the fp32 sums
+        assert (got[k] - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-4), k
