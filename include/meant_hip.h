@@ -193,6 +193,29 @@ int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float*
                    const float* qb, const float* ka, const float* kb, int R, int dtype, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- divided space-time attention glue ----------------------- src/meant/timesformer_pytorch.py:108-145
+ * The fork's TimeSformer regroups the patch tokens between the q|k|v projection and the attention core ('(b n) f' for
+ * the time attention, '(b f) n' for the space attention, the cls key / value in front of every group) and lets the cls
+ * query attend to every token.  The core itself is meant_attn_fwd / _bwd on the regrouped buffer; these move the rows.
+ * dst[r, :] = src[idx[r], :] for idx[r] >= 0, zeros for idx[r] == -1, fill[:] (act [W]) for idx[r] == -2; rows of W
+ * elements, W % 8 == 0.  (Regrouping, its inverse for the outputs, and the cls-token concatenation of :211-213.) */
+int meant_gather_rows(const void* src, const int32_t* idx, const void* fill, void* dst, int64_t n, int64_t W, int dtype,
+                      void* stream);
+/* backward of a regrouping gather with index int32 [G, S] into the L rows of each of B sequences, whose column 0 is
+ * the same (cls) row in every group and whose other entries are a permutation of the remaining rows: dsrc [B, L, W]
+ * is written completely -- dsrc[b, index[g, s]] = ddst[b, g, s] for s >= 1, dsrc[b, index[0, 0]] = sum_g ddst[b, g, 0]. */
+int meant_group_scatter(const void* ddst, const int32_t* index, void* dsrc, int64_t B, int64_t L, int64_t G, int64_t S,
+                        int64_t W, int dtype, void* stream);
+/* cls query: out[b, h*Dh .. +Dh] (row stride ld_out) = softmax_j(scale q[b, 0, h] . k[b, j, h] + (1 - key_mask[b, j]) * -1e9)
+ * v[b, j, h] over all L rows of the packed qkv [B, L, 3*H*Dh] (:116-119, cls_mask :252-253).  stats: float [B, H, 2].
+ * The backward ADDS to dqkv (the buffer meant_group_scatter has filled): dq of row 0, dk and dv of every row.
+ * Dh in {32, 64, 128, 256}; L bounded by the LDS score buffer (~19 k tokens). */
+int meant_attn_cls_fwd(const void* qkv, void* out, int64_t ld_out, float* stats, const float* key_mask, int64_t B, int64_t L,
+                       int H, int Dh, float scale, int dtype, void* stream);
+int meant_attn_cls_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                       const float* stats, const float* key_mask, void* dqkv, int64_t B, int64_t L, int H, int Dh,
+                       float scale, int dtype, void* stream);
+
 /* ---- temporal attention core ----------------------------- meant/temporal.py:44-56
  * q: act [B, H*Dh] (last lag step), kv: act [B*L, 2*H*Dh] packed (k | v); o: act [B, H*Dh];
  * p: float [B, H, L] softmax weights (saved). */

@@ -671,11 +671,10 @@ class meant_vision_pretrainer(nn.Module):
 # to_patch_embedding.*, cls_token, frame_rot_emb.inv_freqs, image_rot_emb.scales, layers.i.{0,1}.{norm.*, fn.to_qkv.weight,
 # fn.to_out.0.*}, layers.i.2.{norm.*, fn.net.0.*, fn.net.3.*}, to_out.{0,1}.*.
 class _TSAttention(nn.Module):
-    """One half of the divided pair (timesformer_pytorch.py:89-148).  On the device: one projection GEMM for all
-    tokens; the cls query's attention over every token (1 x (1 + f n) per head: negligible) in fp32 torch ops; the patch
-    tokens gathered into their groups ('(b n) f' or '(b f) n') with the cls key / value replicated at position 0 of
-    every group, rotated (row 0 of the tables is the identity) and run through the flash attention core; the outputs of
-    position 0 are discarded, the rest scattered back to token order; output projection."""
+    """One half of the divided pair (timesformer_pytorch.py:89-148).  On the device end to end: one projection GEMM for all
+    tokens, ops.divided_attention (row gathers by index tables, rotary with an identity row for the cls position, the
+    flash attention core on the regrouped buffer, the cls query's attention as its own kernel), output projection with the
+    block's `+ x` in the GEMM epilogue."""
 
     def __init__(self, dim, dim_head=64, heads=8):
         super().__init__()
@@ -684,24 +683,9 @@ class _TSAttention(nn.Module):
         self.to_qkv = Linear(dim, inner * 3, bias=False)
         self.to_out = nn.Sequential(Linear(inner, dim), nn.Identity())
 
-    def forward(self, x, mode, f, n, tables, index, residual=None):
-        b, L, _ = x.shape
-        h, dh = self.heads, self.dim_head
-        inner = h * dh
+    def forward(self, x, plan, tables, group_mask=None, cls_mask=None, residual=None):
         qkv = self.to_qkv(x)                                             # [b, 1 + f n, 3 inner]
-        # cls query against all (unrotated) keys / values
-        q0 = qkv[:, :1, :inner].float().view(b, 1, h, dh).transpose(1, 2) * self.scale
-        kk = qkv[:, :, inner:2 * inner].float().view(b, L, h, dh).transpose(1, 2)
-        vv = qkv[:, :, 2 * inner:].float().view(b, L, h, dh).transpose(1, 2)
-        cls_out = (torch.softmax(q0 @ kk.transpose(-1, -2), dim=-1) @ vv).transpose(1, 2).reshape(b, 1, inner).to(x.dtype)
-        # groups: index [G, S] of token positions (position 0 of every group = the cls token)
-        G, S = index.shape
-        grouped = ops.group_gather(qkv, index)                           # [b, G, S, 3 inner]
-        og = ops.attention_core(grouped.reshape(b * G * S, 3 * inner), b * G, S, h, self.scale, tables)
-        og = og.view(b, G, S, inner)[:, :, 1:]                           # drop the cls rows
-        if mode == "time":
-            og = og.transpose(1, 2)                                      # (n, f) -> (f, n)
-        out = torch.cat((cls_out, og.reshape(b, f * n, inner)), dim=1)
+        out = ops.divided_attention(qkv, plan, tables, self.heads, self.scale, group_mask, cls_mask)
         return self.to_out[0](out, residual=residual)                    # the block's `+ x` rides the GEMM epilogue
 
 
@@ -721,15 +705,16 @@ class _TSFeedForward(nn.Module):
 
 
 class TimeSformer(nn.Module):
-    """src/meant/timesformer_pytorch.py:152-259 with rotary embeddings, no token shift, no frame mask (the variants the
-    fork's models use, src/meant/meant_vision.py:130-162).  `meant_forward(video)` returns all tokens [b, 1 + f n, dim],
-    `forward` the class logits of the cls token."""
+    """src/meant/timesformer_pytorch.py:152-259 with rotary embeddings and no token shift (the variants the fork's models
+    use, src/meant/meant_vision.py:130-162), with the optional frame mask.  `meant_forward(video, mask)` returns all
+    tokens [b, 1 + f n, dim], `forward` the class logits of the cls token."""
 
     def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64,
                  attn_dropout=0., ff_dropout=0., rotary_emb=True, shift_tokens=False):
         super().__init__()
         if not rotary_emb or shift_tokens or attn_dropout or ff_dropout:
-            raise NotImplementedError("meant_amd.TimeSformer: only rotary_emb=True, shift_tokens=False, zero dropout are on the path")
+            raise NotImplementedError("meant_amd.TimeSformer: rotary_emb=True, shift_tokens=False, zero dropout (what the fork's "
+                                      "models construct, src/meant/meant_vision.py:130-162) are on the path")
         assert image_size % patch_size == 0, "Image dimensions must be divisible by the patch size."
         self.heads, self.patch_size, self.dim_head, self.num_frames = heads, patch_size, dim_head, num_frames
         self.to_patch_embedding = Linear(channels * patch_size ** 2, dim)
@@ -744,13 +729,18 @@ class TimeSformer(nn.Module):
         self.to_out = nn.Sequential(LayerNorm(dim), Linear(dim, num_classes))
         self._cache = {}
 
-    def _plan(self, f, hp, wp, device):
-        """rotary tables with an identity row for the cls position, and the gather indices of both groupings"""
-        key = (f, hp, wp, str(device))
+    def _plan(self, b, f, hp, wp, device):
+        """rotary tables with an identity row for the cls position, and the int32 index tables of both regroupings for a
+        batch of b videos: index [G, S] (token of group g, position s; position 0 = cls), idx_in [b G S] (rows of the
+        [b L] token matrix that make up the regrouped buffer), idx_out [b L] (row of the regrouped buffer that holds
+        token t's output; -1 for the cls token, whose output comes from its own kernel), idx_dog [b G S] (= idx_in with
+        -1 at position 0: the group attention's output at the cls position is dropped)"""
+        key = (b, f, hp, wp, str(device))
         hit = self._cache.get(key)
         if hit is not None:
             return hit
         n = hp * wp
+        L = 1 + f * n
         with torch.no_grad():
             inv = self.frame_rot_emb.inv_freqs.detach().float().cpu()
             fr = torch.arange(f).float()[:, None] * inv[None, :]
@@ -765,17 +755,34 @@ class TimeSformer(nn.Module):
                 cos = torch.cat((torch.ones(1, a.shape[1]), a.cos())).contiguous().to(device)   # row 0: cls, not rotated
                 sin = torch.cat((torch.zeros(1, a.shape[1]), a.sin())).contiguous().to(device)
                 return (cos, sin, cos, sin)
+
+            def tables_of(index):                                                             # index [G, S] long
+                G, S = index.shape
+                boff = (torch.arange(b) * L)[:, None, None]
+                idx_in = (boff + index[None]).reshape(-1)
+                idx_dog = (boff + index[None]).clone()
+                idx_dog[:, :, 0] = -1
+                pos = torch.full((L,), -1, dtype=torch.long)
+                pos[index[:, 1:].reshape(-1)] = (torch.arange(G)[:, None] * S + torch.arange(1, S)[None, :]).reshape(-1)
+                idx_out = (torch.arange(b) * (G * S))[:, None] + pos[None, :]
+                idx_out[:, 0] = -1
+                i32 = lambda t: t.to(torch.int32).contiguous().to(device)
+                return (i32(index), i32(idx_in), i32(idx_out.reshape(-1)), i32(idx_dog.reshape(-1)))
             tok = 1 + torch.arange(f * n).view(f, n)
             zero = torch.zeros(1, dtype=torch.long)
-            idx_time = torch.stack([torch.cat((zero, tok[:, j])) for j in range(n)]).to(device)   # [n, 1 + f]
-            idx_space = torch.stack([torch.cat((zero, tok[i, :])) for i in range(f)]).to(device)  # [f, 1 + n]
-            plan = (tabs(fr), tabs(ang), idx_time, idx_space)
+            idx_time = torch.stack([torch.cat((zero, tok[:, j])) for j in range(n)])           # [n, 1 + f]
+            idx_space = torch.stack([torch.cat((zero, tok[i, :])) for i in range(f)])          # [f, 1 + n]
+            # cls concatenation at the entry: x[b, 0] = cls (-2: the fill row), x[b, 1 + t] = tokens[b, t]; and its inverse
+            cat_fwd = torch.cat((torch.full((b, 1), -2, dtype=torch.long), torch.arange(b * f * n).view(b, f * n)), dim=1)
+            cat_bwd = (torch.arange(b) * L)[:, None] + 1 + torch.arange(f * n)[None, :]
+            plan = (tabs(fr), tabs(ang), tables_of(idx_time), tables_of(idx_space),
+                    cat_fwd.reshape(-1).to(torch.int32).to(device), cat_bwd.reshape(-1).to(torch.int32).to(device))
         self._cache = {key: plan}
         return plan
 
     def meant_forward(self, video, mask=None):
-        if mask is not None:
-            raise NotImplementedError("meant_amd.TimeSformer: frame masks are not on the path")
+        """mask: optional bool [b, f], False = frame absent (timesformer_pytorch.py:241-253): hidden from the time
+        attention's keys and from the cls query; the space attention masks only the cls query"""
         b, f, c, hh, ww = video.shape
         p = self.patch_size
         assert hh % p == 0 and ww % p == 0, f"height {hh} and width {ww} of video must be divisible by the patch size {p}"
@@ -783,11 +790,17 @@ class TimeSformer(nn.Module):
         n = hp * wp
         dt = resolve_compute_dtype(self, video)
         tokens = self.to_patch_embedding(ops.patchify(video.reshape(b * f, c, hh, ww), p, dt)).view(b, f * n, -1)
-        x = torch.cat((self.cls_token.to(dt)[None].expand(b, -1, -1), tokens), dim=1)
-        t_time, t_space, idx_time, idx_space = self._plan(f, hp, wp, video.device)
+        t_time, t_space, p_time, p_space, cat_fwd, cat_bwd = self._plan(b, f, hp, wp, video.device)
+        x = ops.cls_concat(self.cls_token, tokens, cat_fwd, cat_bwd)
+        time_mask = cls_mask = None
+        if mask is not None:
+            m = mask.to(video.device).float()
+            one = torch.ones(b, 1, device=video.device)
+            time_mask = torch.cat((one, m), dim=1).repeat_interleave(n, dim=0)               # [(b n), 1 + f]: every patch position's group
+            cls_mask = torch.cat((one, m.repeat_interleave(n, dim=1)), dim=1)               # [b, 1 + f n]
         for ta, sa, ff in self.layers:
-            x = ta.fn(ta.norm(x), "time", f, n, t_time, idx_time, residual=x)
-            x = sa.fn(sa.norm(x), "space", f, n, t_space, idx_space, residual=x)
+            x = ta.fn(ta.norm(x), p_time, t_time, time_mask, cls_mask, residual=x)
+            x = sa.fn(sa.norm(x), p_space, t_space, None, cls_mask, residual=x)
             x = ff.fn(ff.norm(x), residual=x)
         return x
 

@@ -1146,26 +1146,100 @@ def geglu(h):
     return _GEGLU.apply(h)
 
 
-class _GroupGather(torch.autograd.Function):
-    """x[:, index] for an index [G, S] whose column 0 is the same row (the cls token) in every group and whose other
-    entries are a permutation of the remaining rows: the backward is a copy (no atomics) plus one sum for the cls row"""
+def gather_rows(src2d, idx, fill=None):
+    """dst[r] = src2d[idx[r]] (idx int32 on the device; -1 -> zeros, -2 -> `fill` row); no autograd"""
+    _need_gpu(src2d, idx)
+    src2d = _c(src2d)
+    n, W = idx.numel(), src2d.shape[1]
+    dst = torch.empty((n, W), device=src2d.device, dtype=src2d.dtype)
+    check(lib.meant_gather_rows(_p(src2d), _p(idx), _p(fill), _p(dst), n, W, _dt(src2d), _stream()), "gather_rows")
+    return dst
+
+
+class _DividedAttention(torch.autograd.Function):
+    """One half of the divided space-time pair between the q|k|v projection and the output projection
+    (src/meant/timesformer_pytorch.py:108-145), entirely on the HIP path:
+      forward : rows regrouped by an index table (meant_gather_rows; the cls row in front of every group) -> rotary in place
+                (identity row for the cls position) -> flash attention core -> rows back to token order by the inverse
+                table -> the cls query's attention over all tokens written into row 0 (meant_attn_cls_fwd);
+      backward: the same tables in reverse, the attention backward with the rotary adjoint inside, meant_group_scatter
+                (copy of the group rows, sum of the cls rows), and the cls backward ADDING into that buffer.
+    qkv [b, L, 3*H*Dh] -> out [b, L, H*Dh].  plan = (index [G, S] int32, idx_in [b*G*S], idx_out [b*L], idx_dog [b*G*S])."""
 
     @staticmethod
-    def forward(ctx, x, index):
-        ctx.save_for_backward(index)
-        ctx.rows = x.shape[1]
+    def forward(ctx, qkv, plan, tables, H, scale, group_mask, cls_mask):
+        _need_gpu(qkv)
+        qkv = _c(qkv)
+        b, L, D3 = qkv.shape
+        D = D3 // 3
+        Dh = D // H
+        index, idx_in, idx_out, idx_dog = plan
         G, S = index.shape
-        return x.index_select(1, index.reshape(-1)).view(x.shape[0], G, S, x.shape[-1])
+        dt = _dt(qkv)
+        q2 = qkv.view(b * L, D3)
+        grouped = gather_rows(q2, idx_in)                                       # [b G S, 3 D]
+        qa, qb, ka, kb = tables
+        check(lib.meant_rotary_qk(_p(grouped), b * G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()), "rotary_qk")
+        og = torch.empty((b * G * S, D), device=qkv.device, dtype=qkv.dtype)
+        lse = torch.empty((b * G, H, S, 2), device=qkv.device, dtype=torch.float32)
+        km = _c(group_mask.float()) if group_mask is not None else None         # [b G, S]
+        wsb = lib.meant_attn_ws(b * G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=qkv.device, dtype=torch.uint8)
+        check(lib.meant_attn_fwd(_p(grouped), _p(og), _p(lse), _p(km), b * G, S, H, Dh, float(scale), 0, dt, _p(ws), wsb, _stream()), "attn_fwd")
+        out = gather_rows(og, idx_out).view(b, L, D)                             # row 0 of every sequence: zeros for now
+        stats = torch.empty((b, H, 2), device=qkv.device, dtype=torch.float32)
+        cm = _c(cls_mask.float()) if cls_mask is not None else None             # [b, L]
+        check(lib.meant_attn_cls_fwd(_p(q2), _p(out), L * D, _p(stats), _p(cm), b, L, H, Dh, float(scale), dt, _stream()), "attn_cls_fwd")
+        ctx.save_for_backward(qkv, grouped, og, lse, km, out, stats, cm)
+        ctx.plan, ctx.tables, ctx.meta = plan, tables, (b, L, D, H, Dh, G, S, float(scale))
+        return out
 
     @staticmethod
     def backward(ctx, dout):
-        (index,) = ctx.saved_tensors
-        b, G, S, d = dout.shape
-        dx = dout.new_empty((b, ctx.rows, d))
-        dx.index_copy_(1, index[:, 1:].reshape(-1), dout[:, :, 1:].reshape(b, G * (S - 1), d))
-        dx[:, index[0, 0]] = dout[:, :, 0].sum(dim=1)
-        return dx, None
+        qkv, grouped, og, lse, km, out, stats, cm = ctx.saved_tensors
+        b, L, D, H, Dh, G, S, scale = ctx.meta
+        index, idx_in, idx_out, idx_dog = ctx.plan
+        dout = _c(dout)
+        dt = _dt(dout)
+        dog = gather_rows(dout.view(b * L, D), idx_dog)                          # position 0 of every group: zeros (its output was dropped)
+        dgrouped = torch.empty_like(grouped)
+        wsb = lib.meant_attn_ws(b * G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=dout.device, dtype=torch.uint8)
+        qa, qb, ka, kb = ctx.tables
+        check(lib.meant_attn_bwd(_p(grouped), _p(og), _p(dog), _p(lse), _p(km), _p(dgrouped), b * G, S, H, Dh, scale, 0,
+                                 _p(qa), _p(qb), _p(ka), _p(kb), qa.shape[1], dt, _p(ws), wsb, _stream()), "attn_bwd")
+        dqkv = torch.empty_like(qkv)
+        check(lib.meant_group_scatter(_p(dgrouped), _p(index), _p(dqkv), b, L, G, S, 3 * D, dt, _stream()), "group_scatter")
+        check(lib.meant_attn_cls_bwd(_p(qkv), _p(out), L * D, _p(dout), L * D, _p(stats), _p(cm), _p(dqkv), b, L, H, Dh, scale, dt, _stream()),
+              "attn_cls_bwd")
+        return dqkv, None, None, None, None, None, None
 
 
-def group_gather(x, index):
-    return _GroupGather.apply(x, index)
+def divided_attention(qkv, plan, tables, H, scale, group_mask=None, cls_mask=None):
+    return _DividedAttention.apply(qkv, plan, tables, int(H), float(scale), group_mask, cls_mask)
+
+
+class _ClsConcat(torch.autograd.Function):
+    """torch.cat((cls_token expanded over the batch, tokens), dim=1) (src/meant/timesformer_pytorch.py:211-213) as one row
+    gather: x[b, 0] = cls, x[b, 1 + t] = tokens[b, t]"""
+
+    @staticmethod
+    def forward(ctx, cls_token, tokens, idx_fwd, idx_bwd):
+        _need_gpu(cls_token, tokens)
+        b, n, d = tokens.shape
+        fill = _c(cls_token.detach().to(tokens.dtype).reshape(d))
+        x = gather_rows(_c(tokens).view(b * n, d), idx_fwd, fill).view(b, n + 1, d)
+        ctx.idx_bwd, ctx.shape, ctx.cls_shape = idx_bwd, (b, n, d), cls_token.shape
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        b, n, d = ctx.shape
+        dx = _c(dx)
+        dtok = gather_rows(dx.view(b * (n + 1), d), ctx.idx_bwd).view(b, n, d)
+        dcls = dx[:, 0, :].float().sum(dim=0).view(ctx.cls_shape)          # b rows of d: plumbing-sized
+        return dcls, dtok, None, None
+
+
+def cls_concat(cls_token, tokens, idx_fwd, idx_bwd):
+    return _ClsConcat.apply(cls_token, tokens, idx_fwd, idx_bwd)

@@ -470,13 +470,18 @@ class _TSAttention(nn.Module):
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Identity())      # Dropout(0.) at index 1 in the reference
 
-    def forward(self, x, mode, f, n, rot):
+    def forward(self, x, mode, f, n, rot, mask=None, cls_mask=None):
+        """mask: bool [b, 1 + f] over a time group's keys (cls, frames) -- the time attention only (:250, :256); cls_mask: bool
+        [b, 1 + f n] over the keys of the cls query (:252-253, :256-257); masked scores are filled with -max (:82-84)"""
         b, _, _ = x.shape
         h = self.heads
         q, k, v = self.to_qkv(x).chunk(3, dim=-1)
         split = lambda t: t.reshape(b, -1, h, t.shape[-1] // h).permute(0, 2, 1, 3)       # b h tokens d
         q, k, v = split(q) * self.scale, split(k), split(v)
-        cls_out = torch.softmax(q[:, :, :1] @ k.transpose(-1, -2), dim=-1) @ v               # b h 1 d
+        sim0 = q[:, :, :1] @ k.transpose(-1, -2)                                             # b h 1 tokens
+        if cls_mask is not None:
+            sim0 = sim0.masked_fill(~cls_mask[:, None, None, :], -torch.finfo(sim0.dtype).max)
+        cls_out = torch.softmax(sim0, dim=-1) @ v                                            # b h 1 d
         d = q.shape[-1]
 
         def group(t):                                                                        # patch tokens -> groups
@@ -489,7 +494,10 @@ class _TSAttention(nn.Module):
         ck = k[:, :, :1].unsqueeze(2).expand(b, h, G, 1, d)
         cv = v[:, :, :1].unsqueeze(2).expand(b, h, G, 1, d)
         kg, vg = torch.cat((ck, kg), dim=3), torch.cat((cv, vg), dim=3)
-        og = torch.softmax(qg @ kg.transpose(-1, -2), dim=-1) @ vg                           # b h G L d
+        sim = qg @ kg.transpose(-1, -2)                                                      # b h G L L
+        if mask is not None:
+            sim = sim.masked_fill(~mask[:, None, None, None, :], -torch.finfo(sim.dtype).max)
+        og = torch.softmax(sim, dim=-1) @ vg                                                 # b h G L d
         if mode == "time":
             og = og.permute(0, 1, 3, 2, 4)                                                   # b h f n d
         out = torch.cat((cls_out, og.reshape(b, h, f * n, d)), dim=2)
@@ -515,8 +523,8 @@ class _TSFeedForward(nn.Module):
 
 
 class TimeSformer(nn.Module):
-    """src/meant/timesformer_pytorch.py:152-259 with rotary_emb=True, shift_tokens=False, no frame mask (what the
-    fork's callers use, src/meant/meant_vision.py:130-162).  Frame rotary: angle = frame * 10000^(-2j/Dh) laid out
+    """src/meant/timesformer_pytorch.py:152-259 with rotary_emb=True, shift_tokens=False (what the fork's callers use,
+    src/meant/meant_vision.py:130-162), with the optional frame mask.  Frame rotary: angle = frame * 10000^(-2j/Dh) laid out
     cat(freqs, freqs) (src/utils/rotary.py:51-62); axial rotary: logspace(0, log2(max_freq/2), Dh/4, base 2) * pi *
     linspace(-1, 1) along h then w, each angle repeated on a lane pair (:21-49); both rotate adjacent pairs."""
 
@@ -544,7 +552,8 @@ class TimeSformer(nn.Module):
         ang = ang.repeat_interleave(2, dim=-1)                                                # [n, Dh]
         return (fr.sin(), fr.cos()), (ang.sin(), ang.cos())
 
-    def meant_forward(self, video):
+    def meant_forward(self, video, mask=None):
+        """mask: optional bool [b, f], False = frame absent (:241-253)"""
         b, f, c, hh, ww = video.shape
         p = self.patch_size
         hp, wp = hh // p, ww // p
@@ -552,14 +561,19 @@ class TimeSformer(nn.Module):
         tok = video.reshape(b, f, c, hp, p, wp, p).permute(0, 1, 3, 5, 4, 6, 2).reshape(b, f * n, p * p * c)   # (p1 p2 c)
         x = torch.cat((self.cls_token[None].expand(b, -1, -1), self.to_patch_embedding(tok)), dim=1)
         frame_rot, image_rot = self.rotary_tables(f, hp, wp)
+        frame_mask = cls_mask = None
+        if mask is not None:
+            one = torch.ones(b, 1, dtype=torch.bool)
+            frame_mask = torch.cat((one, mask), dim=1)                                            # [b, 1 + f]
+            cls_mask = torch.cat((one, mask.repeat_interleave(n, dim=1)), dim=1)                  # [b, 1 + f n] ('b f -> b (f n)')
         for ta, sa, ff in self.layers:
-            x = ta.fn(ta.norm(x), "time", f, n, frame_rot) + x
-            x = sa.fn(sa.norm(x), "space", f, n, image_rot) + x
+            x = ta.fn(ta.norm(x), "time", f, n, frame_rot, mask=frame_mask, cls_mask=cls_mask) + x
+            x = sa.fn(sa.norm(x), "space", f, n, image_rot, cls_mask=cls_mask) + x
             x = ff.fn(ff.norm(x)) + x
         return x
 
-    def forward(self, video):
-        return self.to_out(self.meant_forward(video)[:, 0])
+    def forward(self, video, mask=None):
+        return self.to_out(self.meant_forward(video, mask=mask)[:, 0])
 
 
 class meant_language_pretrainer(nn.Module):

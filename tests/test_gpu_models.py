@@ -329,18 +329,24 @@ def test_mim_pretrainer_golden(dev, golden, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_timesformer_golden(dev, golden, dtype):
-    """divided space-time attention (time then space, cls token, frame + axial rotary, GEGLU)
-    against the fork's TimeSformer (fixture from src/meant/timesformer_pytorch.py)"""
+@pytest.mark.parametrize("fixture", ["timesformer_tiny", "timesformer_tiny_mask"])
+def test_timesformer_golden(dev, golden, dtype, fixture):
+    """divided space-time attention (time then space, cls token, frame + axial rotary, GEGLU; with and
+    without the frame mask) against the fork's TimeSformer (fixtures from src/meant/timesformer_pytorch.py).  The whole
+    attention half runs on the HIP path: row gathers, flash core, cls-query kernel (route counter)."""
     import meant_amd as M
+    from meant_amd import _lib
     from oracle import meant_oracle as O
-    g = golden("timesformer_tiny")
+    g = golden(fixture)
     torch.manual_seed(0)
     m = M.TimeSformer(dim=128, num_frames=3, num_classes=5, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64)
     O.fill_weights_(m, 8642)
     m = m.to(dev).eval()
     m.compute_dtype = dtype
-    x = m.meant_forward(torch.from_numpy(g["video"]).to(dev))
+    mask = torch.from_numpy(g["mask"]).to(dev) if "mask" in g.files else None
+    _lib.route_reset()
+    x = m.meant_forward(torch.from_numpy(g["video"]).to(dev), mask=mask)
+    assert _lib.route_count("attn_cls") == 4                 # 2 layers x (time, space): the cls query's attention is a HIP kernel
     logits = m.to_out(x[:, 0])
     assert x.shape == (2, 13, 128) and logits.shape == (2, 5)
     tol = 2e-4 if dtype == torch.float32 else 4e-2
