@@ -216,6 +216,15 @@ int meant_attn_cls_bwd(const void* qkv, const void* out, int64_t ld_out, const v
                        const float* stats, const float* key_mask, void* dqkv, int64_t B, int64_t L, int H, int Dh,
                        float scale, int dtype, void* stream);
 
+/* time token shift of the patch tokens of x act [B, 1 + frames*n, d] (PreTokenShift, src/meant/timesformer_pytorch.py:28-53):
+ * columns [0, d/3) from the next frame, [d/3, 2d/3) unchanged, [2d/3, 3(d/3)) from the previous frame, zeros beyond the
+ * clip's ends; the cls row and any remainder columns pass through.  transpose != 0: the adjoint (backward).  x != y. */
+int meant_token_shift(const void* x, void* y, int64_t B, int64_t frames, int64_t n, int64_t d, int transpose, int dtype,
+                      void* stream);
+/* inverted dropout y = x * keep / (1 - p) (nn.Dropout at :70,:101): counter-based mask from (seed, element index), so the
+ * backward is the same call on dy.  n % 8 == 0. */
+int meant_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+
 /* ---- temporal attention core ----------------------------- meant/temporal.py:44-56
  * q: act [B, H*Dh] (last lag step), kv: act [B*L, 2*H*Dh] packed (k | v); o: act [B, H*Dh];
  * p: float [B, H, L] softmax weights (saved). */

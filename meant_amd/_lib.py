@@ -50,6 +50,8 @@ SIGNATURES = {
     "meant_group_scatter": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p]),
     "meant_attn_cls_fwd": (_i, [_p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _f, _i, _p]),
     "meant_attn_cls_bwd": (_i, [_p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _p]),
+    "meant_token_shift": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i, _i, _p]),
+    "meant_dropout": (_i, [_p, _p, _i64, _f, _u64, _i, _p]),
     "meant_temporal_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
     "meant_temporal_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
     "meant_patchify": (_i, [_p, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),

@@ -207,6 +207,51 @@ __global__ __launch_bounds__(DIV_THREADS) void attn_cls_bwd_kernel(const T* __re
   }
 }
 
+// time token shift (src/meant/timesformer_pytorch.py:28-53): of the patch tokens [b, f, n, d] the first d/3 columns come from
+// the NEXT frame, the second third stays, the third third comes from the PREVIOUS frame (zeros beyond the clip's ends); the
+// cls row and the columns past 3 * (d / 3) pass through.  transpose = the adjoint (the two shifts swap).
+template <typename T>
+__global__ __launch_bounds__(DIV_THREADS) void token_shift_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t B, int f, int n, int d,
+                                                                   int chunk, int transpose) {
+  const int nch = d >> 3;
+  const int64_t L = 1 + (int64_t)f * n, total = B * L * nch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const int64_t row = i / nch, b = row / L, t = row - b * L;
+    int64_t src = row;
+    bool zero = false;
+    if (t > 0) {
+      const int which = (ch * 8) / chunk;              // 0, 1, 2: shifted thirds; >= 3: the remainder columns
+      int sh = which == 0 ? 1 : (which == 2 ? -1 : 0); // source frame = frame + sh
+      if (transpose) sh = -sh;
+      const int fi = (int)((t - 1) / n) + sh;
+      zero = fi < 0 || fi >= f;
+      src = row + (int64_t)sh * n;
+    }
+    Vec8<T> v;
+    if (zero) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.set(k, 0.f);
+    } else v = load8<T>(x + src * d + ch * 8);
+    store8<T>(y + row * d + ch * 8, v);
+  }
+}
+
+// inverted dropout y = x * keep / (1 - p) with the counter-based mask of the fused RMSNorm dropout (common.h keep_scale8): the
+// same (seed, element index) gives the same mask, so the backward is the same call on dy
+template <typename T>
+__global__ __launch_bounds__(DIV_THREADS) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n8, float p, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float km[8];
+    keep_scale8(p, seed, (uint64_t)i * 8, km);
+    const Vec8<T> v = load8<T>(x + i * 8);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.set(k, v.get(k) * km[k]);
+    store8<T>(y + i * 8, o);
+  }
+}
+
 inline int rows_blocks(int64_t n) {
   int64_t b = ceil_div(n, 4);
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -281,5 +326,28 @@ extern "C" int meant_attn_cls_bwd(const void* qkv, const void* out, int64_t ld_o
   if (dtype == MEANT_F32) LAUNCH_CLS_B(float) else if (dtype == MEANT_BF16) LAUNCH_CLS_B(bf16) else { meant_set_error("attn_cls_bwd: unknown dtype"); return MEANT_ERR_ARG; }
 #undef LAUNCH_CLS_B
   MEANT_LAUNCH_CHECK("attn_cls_bwd");
+  return MEANT_OK;
+}
+
+extern "C" int meant_token_shift(const void* x, void* y, int64_t B, int64_t frames, int64_t n, int64_t d, int transpose, int dtype, void* stream) {
+  DIV_REQ(x && y && x != y && B > 0 && frames > 0 && n > 0 && d >= 24 && d % 8 == 0 && (d / 3) % 8 == 0 && frames * n < (1LL << 30),
+          "token_shift: bad argument (d / 3 must be a multiple of 8)");
+  DIV_REQ(meant_aligned16(x) && meant_aligned16(y), "token_shift: 16-byte alignment");
+  const int64_t total = B * (1 + frames * n) * (d / 8);
+  int64_t nb = ceil_div(total, DIV_THREADS);
+  if (nb > 8192) nb = 8192;
+  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(token_shift_kernel<T>, dim3((unsigned)nb), dim3(DIV_THREADS), 0, (hipStream_t)stream, (const T*)x, (T*)y,
+                                              B, (int)frames, (int)n, (int)d, (int)(d / 3), transpose));
+  MEANT_LAUNCH_CHECK("token_shift");
+  return MEANT_OK;
+}
+
+extern "C" int meant_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  DIV_REQ(x && y && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "dropout: bad argument (n must be a multiple of 8, 0 <= p < 1)");
+  DIV_REQ(meant_aligned16(x) && meant_aligned16(y), "dropout: 16-byte alignment");
+  int64_t nb = ceil_div(n / 8, DIV_THREADS);
+  if (nb > 8192) nb = 8192;
+  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dropout_kernel<T>, dim3((unsigned)nb), dim3(DIV_THREADS), 0, (hipStream_t)stream, (const T*)x, (T*)y, n / 8, p, seed));
+  MEANT_LAUNCH_CHECK("dropout");
   return MEANT_OK;
 }

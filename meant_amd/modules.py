@@ -683,9 +683,11 @@ class _TSAttention(nn.Module):
         self.to_qkv = Linear(dim, inner * 3, bias=False)
         self.to_out = nn.Sequential(Linear(inner, dim), nn.Identity())
 
-    def forward(self, x, plan, tables, group_mask=None, cls_mask=None, residual=None):
+    def forward(self, x, plan, tables, group_mask=None, cls_mask=None, residual=None, drop_p=0.0):
         qkv = self.to_qkv(x)                                             # [b, 1 + f n, 3 inner]
         out = ops.divided_attention(qkv, plan, tables, self.heads, self.scale, group_mask, cls_mask)
+        if drop_p > 0.0:                                                 # Dropout after to_out (:101) sits before the block's `+ x`
+            return ops.dropout(self.to_out[0](out), drop_p, _seed()) + residual
         return self.to_out[0](out, residual=residual)                    # the block's `+ x` rides the GEMM epilogue
 
 
@@ -695,13 +697,28 @@ class _TSPreNorm(nn.Module):
         self.fn, self.norm = fn, LayerNorm(dim)
 
 
+class _TSPreTokenShift(nn.Module):
+    """PreTokenShift (timesformer_pytorch.py:34-53): shifts thirds of the features of the patch tokens one frame forward /
+    backward in time before calling `fn`; keeps the reference's module nesting (state_dict keys `...fn.fn.*`)"""
+
+    def __init__(self, frames, fn):
+        super().__init__()
+        self.frames, self.fn = frames, fn
+
+    def forward(self, x, *args, **kw):
+        return self.fn(ops.token_shift(x, self.frames, (x.shape[1] - 1) // self.frames), *args, **kw)
+
+
 class _TSFeedForward(nn.Module):
     def __init__(self, dim, mult=4):
         super().__init__()
         self.net = nn.Sequential(Linear(dim, dim * mult * 2), nn.Identity(), nn.Identity(), Linear(dim * mult, dim))
 
-    def forward(self, x, residual=None):
-        return self.net[3](ops.geglu(self.net[0](x)), residual=residual)
+    def forward(self, x, residual=None, drop_p=0.0):
+        h = ops.geglu(self.net[0](x))
+        if drop_p > 0.0:                                                 # Dropout between GEGLU and the second Linear (:70)
+            h = ops.dropout(h, drop_p, _seed())
+        return self.net[3](h, residual=residual)
 
 
 class TimeSformer(nn.Module):
@@ -712,9 +729,10 @@ class TimeSformer(nn.Module):
     def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64,
                  attn_dropout=0., ff_dropout=0., rotary_emb=True, shift_tokens=False):
         super().__init__()
-        if not rotary_emb or shift_tokens or attn_dropout or ff_dropout:
-            raise NotImplementedError("meant_amd.TimeSformer: rotary_emb=True, shift_tokens=False, zero dropout (what the fork's "
-                                      "models construct, src/meant/meant_vision.py:130-162) are on the path")
+        if not rotary_emb:
+            raise NotImplementedError("meant_amd.TimeSformer: rotary_emb=True (what the fork's models construct, "
+                                      "src/meant/meant_vision.py:130-162) is on the path; the learned-position variant is not")
+        self.shift_tokens, self.attn_dropout, self.ff_dropout = bool(shift_tokens), float(attn_dropout), float(ff_dropout)
         assert image_size % patch_size == 0, "Image dimensions must be divisible by the patch size."
         self.heads, self.patch_size, self.dim_head, self.num_frames = heads, patch_size, dim_head, num_frames
         self.to_patch_embedding = Linear(channels * patch_size ** 2, dim)
@@ -723,9 +741,10 @@ class TimeSformer(nn.Module):
         self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
         self.image_rot_emb = nn.Module()
         self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
-        self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
-                                                    _TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
-                                                    _TSPreNorm(dim, _TSFeedForward(dim))]) for _ in range(depth)])
+        wrap = (lambda fn: _TSPreTokenShift(num_frames, fn)) if shift_tokens else (lambda fn: fn)      # :196-199
+        self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
+                                                    _TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
+                                                    _TSPreNorm(dim, wrap(_TSFeedForward(dim)))]) for _ in range(depth)])
         self.to_out = nn.Sequential(LayerNorm(dim), Linear(dim, num_classes))
         self._cache = {}
 
@@ -798,10 +817,12 @@ class TimeSformer(nn.Module):
             one = torch.ones(b, 1, device=video.device)
             time_mask = torch.cat((one, m), dim=1).repeat_interleave(n, dim=0)               # [(b n), 1 + f]: every patch position's group
             cls_mask = torch.cat((one, m.repeat_interleave(n, dim=1)), dim=1)               # [b, 1 + f n]
-        for ta, sa, ff in self.layers:
-            x = ta.fn(ta.norm(x), p_time, t_time, time_mask, cls_mask, residual=x)
-            x = sa.fn(sa.norm(x), p_space, t_space, None, cls_mask, residual=x)
-            x = ff.fn(ff.norm(x), residual=x)
+        pa = self.attn_dropout if self.training else 0.0
+        pf = self.ff_dropout if self.training else 0.0
+        for ta, sa, ff in self.layers:                   # .fn is the block itself, or PreTokenShift around it (:196-199)
+            x = ta.fn(ta.norm(x), p_time, t_time, time_mask, cls_mask, residual=x, drop_p=pa)
+            x = sa.fn(sa.norm(x), p_space, t_space, None, cls_mask, residual=x, drop_p=pa)
+            x = ff.fn(ff.norm(x), residual=x, drop_p=pf)
         return x
 
     def forward(self, video, mask=None):

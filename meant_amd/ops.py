@@ -1219,6 +1219,53 @@ def divided_attention(qkv, plan, tables, H, scale, group_mask=None, cls_mask=Non
     return _DividedAttention.apply(qkv, plan, tables, int(H), float(scale), group_mask, cls_mask)
 
 
+class _TokenShift(torch.autograd.Function):
+    """PreTokenShift (src/meant/timesformer_pytorch.py:28-53) on x [b, 1 + f n, d]"""
+
+    @staticmethod
+    def forward(ctx, x, f, n):
+        _need_gpu(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib.meant_token_shift(_p(x), _p(y), x.shape[0], f, n, x.shape[2], 0, _dt(x), _stream()), "token_shift")
+        ctx.fn = (f, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib.meant_token_shift(_p(dy), _p(dx), dy.shape[0], ctx.fn[0], ctx.fn[1], dy.shape[2], 1, _dt(dy), _stream()), "token_shift")
+        return dx, None, None
+
+
+def token_shift(x, f, n):
+    return _TokenShift.apply(x, int(f), int(n))
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _need_gpu(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib.meant_dropout(_p(x), _p(y), x.numel(), p, seed, _dt(x), _stream()), "dropout")
+        ctx.args = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib.meant_dropout(_p(dy), _p(dx), dy.numel(), ctx.args[0], ctx.args[1], _dt(dy), _stream()), "dropout")
+        return dx, None, None
+
+
+def dropout(x, p: float, seed: int):
+    """inverted dropout with a counter-based mask (statistically nn.Dropout; the mask is not torch's)"""
+    return x if p <= 0.0 else _Dropout.apply(x, float(p), int(seed))
+
+
 class _ClsConcat(torch.autograd.Function):
     """torch.cat((cls_token expanded over the batch, tokens), dim=1) (src/meant/timesformer_pytorch.py:211-213) as one row
     gather: x[b, 0] = cls, x[b, 1 + t] = tokens[b, t]"""

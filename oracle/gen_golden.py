@@ -328,6 +328,37 @@ def gen_timesformer(R):
     save("timesformer_tiny", **arrs)
 
 
+def gen_timesformer_shift(R):
+    """the same with shift_tokens=True (PreTokenShift, src/meant/timesformer_pytorch.py:28-53,196-199), dim 192 so that the
+    thirds are 64 features wide, 4 frames"""
+    import types
+    from oracle.meant_oracle import fill_weights_
+    for name in ("src", "src.utils", "src.meant"):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name); pkg.__path__ = []; sys.modules[name] = pkg
+    _load("src.utils.rotary", f"{REF}/src/utils/rotary.py")
+    ref = _load("src.meant.timesformer_pytorch", f"{REF}/src/meant/timesformer_pytorch.py")
+    torch.manual_seed(0)
+    m = ref.TimeSformer(dim=192, num_frames=4, num_classes=3, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64,
+                        shift_tokens=True).eval()
+    fill_weights_(m, 8643)
+    r = np.random.RandomState(108)
+    video = r.standard_normal((2, 4, 4, 32, 32)).astype("float32")
+    x = m.meant_forward(torch.from_numpy(video))
+    logits = m.to_out(x[:, 0])
+    tgt = np.array([2, 0])
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(tgt)) + 0.01 * x.pow(2).mean()
+    loss.backward()
+    names, norms = grads_of(m)
+    params = dict(m.named_parameters())
+    arrs = dict(video=video, target=tgt, tokens=_np(x), logits=_np(logits), loss=np.array(loss.item(), dtype="float64"),
+                grad_names=np.array(names), grad_norms=norms)
+    for k in ["cls_token", "layers.0.0.fn.fn.to_qkv.weight", "layers.1.2.fn.fn.net.0.bias", "to_patch_embedding.bias"]:
+        g = params[k].grad
+        arrs["grad__" + k] = _np(g if g.numel() <= 4096 else g[:4])
+    save("timesformer_tiny_shift", **arrs)
+
+
 def gen_timesformer_mask(R):
     """the same with a frame mask (src/meant/timesformer_pytorch.py:241-253: `mask` [b, f] bool hides whole frames from the
     time attention's keys and from the cls query; the space attention only masks the cls query): video 0 loses its last
@@ -363,7 +394,7 @@ def gen_timesformer_mask(R):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
         torch.set_num_threads(8)
-        {"mlm": gen_mlm, "mim": gen_mim, "timesformer": gen_timesformer, "timesformer_mask": gen_timesformer_mask}[sys.argv[2]](load_reference())
+        {"mlm": gen_mlm, "mim": gen_mim, "timesformer": gen_timesformer, "timesformer_mask": gen_timesformer_mask, "timesformer_shift": gen_timesformer_shift}[sys.argv[2]](load_reference())
     else:
         main()
         R_ = load_reference()
@@ -371,3 +402,4 @@ if __name__ == "__main__":
         gen_mim(R_)
         gen_timesformer(R_)
         gen_timesformer_mask(R_)
+        gen_timesformer_shift(R_)

@@ -522,13 +522,36 @@ class _TSFeedForward(nn.Module):
         return self.net[3](a * F.gelu(g))
 
 
+class _TSPreTokenShift(nn.Module):
+    """src/meant/timesformer_pytorch.py:28-53: of the patch tokens [b, f, n, d] the first d // 3 features are taken from the
+    next frame (shift -1: F.pad drops the first frame and appends zeros), the second third is kept, the third third comes
+    from the previous frame (shift +1); features past 3 * (d // 3) and the cls token pass through"""
+
+    def __init__(self, frames, fn):
+        super().__init__()
+        self.frames, self.fn = frames, fn
+
+    def forward(self, x, *args, **kw):
+        f, d = self.frames, x.shape[-1]
+        cls_x, t = x[:, :1], x[:, 1:]
+        b = t.shape[0]
+        t = t.reshape(b, f, -1, d)
+        c = d // 3
+        z = torch.zeros_like(t[:, :1, :, :c])
+        nxt = torch.cat((t[:, 1:, :, :c], z), dim=1)                    # out[frame] = in[frame + 1]
+        prv = torch.cat((z, t[:, :-1, :, 2 * c:3 * c]), dim=1)          # out[frame] = in[frame - 1]
+        t = torch.cat((nxt, t[..., c:2 * c], prv, t[..., 3 * c:]), dim=-1).reshape(b, -1, d)
+        return self.fn(torch.cat((cls_x, t), dim=1), *args, **kw)
+
+
 class TimeSformer(nn.Module):
     """src/meant/timesformer_pytorch.py:152-259 with rotary_emb=True, shift_tokens=False (what the fork's callers use,
     src/meant/meant_vision.py:130-162), with the optional frame mask.  Frame rotary: angle = frame * 10000^(-2j/Dh) laid out
     cat(freqs, freqs) (src/utils/rotary.py:51-62); axial rotary: logspace(0, log2(max_freq/2), Dh/4, base 2) * pi *
     linspace(-1, 1) along h then w, each angle repeated on a lane pair (:21-49); both rotate adjacent pairs."""
 
-    def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64):
+    def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64,
+                 shift_tokens=False):
         super().__init__()
         self.heads, self.patch_size, self.dim_head = heads, patch_size, dim_head
         self.to_patch_embedding = nn.Linear(channels * patch_size ** 2, dim)
@@ -537,9 +560,10 @@ class TimeSformer(nn.Module):
         self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
         self.image_rot_emb = nn.Module()
         self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
-        self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
-                                                    _TSPreNorm(dim, _TSAttention(dim, dim_head, heads)),
-                                                    _TSPreNorm(dim, _TSFeedForward(dim))]) for _ in range(depth)])
+        wrap = (lambda fn: _TSPreTokenShift(num_frames, fn)) if shift_tokens else (lambda fn: fn)      # :196-199
+        self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
+                                                    _TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
+                                                    _TSPreNorm(dim, wrap(_TSFeedForward(dim)))]) for _ in range(depth)])
         self.to_out = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
 
     def rotary_tables(self, f, hp, wp):

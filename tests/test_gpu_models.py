@@ -329,7 +329,7 @@ def test_mim_pretrainer_golden(dev, golden, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("fixture", ["timesformer_tiny", "timesformer_tiny_mask"])
+@pytest.mark.parametrize("fixture", ["timesformer_tiny", "timesformer_tiny_mask", "timesformer_tiny_shift"])
 def test_timesformer_golden(dev, golden, dtype, fixture):
     """divided space-time attention (time then space, cls token, frame + axial rotary, GEGLU; with and
     without the frame mask) against the fork's TimeSformer (fixtures from src/meant/timesformer_pytorch.py).  The whole
@@ -339,8 +339,11 @@ def test_timesformer_golden(dev, golden, dtype, fixture):
     from oracle import meant_oracle as O
     g = golden(fixture)
     torch.manual_seed(0)
-    m = M.TimeSformer(dim=128, num_frames=3, num_classes=5, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64)
-    O.fill_weights_(m, 8642)
+    from tests.test_oracle_golden import TS_CFG
+    cfg = dict(TS_CFG[fixture])
+    seed = cfg.pop("seed")
+    m = M.TimeSformer(image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64, **cfg)
+    O.fill_weights_(m, seed)
     m = m.to(dev).eval()
     m.compute_dtype = dtype
     mask = torch.from_numpy(g["mask"]).to(dev) if "mask" in g.files else None
@@ -348,7 +351,7 @@ def test_timesformer_golden(dev, golden, dtype, fixture):
     x = m.meant_forward(torch.from_numpy(g["video"]).to(dev), mask=mask)
     assert _lib.route_count("attn_cls") == 4                 # 2 layers x (time, space): the cls query's attention is a HIP kernel
     logits = m.to_out(x[:, 0])
-    assert x.shape == (2, 13, 128) and logits.shape == (2, 5)
+    assert x.shape == (2, 1 + cfg["num_frames"] * 4, cfg["dim"]) and logits.shape == (2, cfg["num_classes"])
     tol = 2e-4 if dtype == torch.float32 else 4e-2
     assert (x.float().cpu() - torch.from_numpy(g["tokens"])).abs().max().item() < tol * float(np.abs(g["tokens"]).max())
     assert (logits.float().cpu() - torch.from_numpy(g["logits"])).abs().max().item() < tol * max(1.0, float(np.abs(g["logits"]).max()))
@@ -367,6 +370,23 @@ def test_timesformer_golden(dev, golden, dtype, fixture):
             ref = torch.from_numpy(g[k])
             got = (p_.grad if p_.grad.numel() <= 4096 else p_.grad[:4]).float().cpu()
             assert (got - ref).abs().max().item() <= tol_g * max(ref.abs().max().item(), floor), k
+
+
+@pytest.mark.gpu
+def test_dropout_kernel_statistics_and_backward(dev):
+    """meant_dropout (the TimeSformer's attention / feed-forward dropouts, src/meant/timesformer_pytorch.py:70,101): keep rate
+    1 - p, survivors scaled by 1 / (1 - p), the same mask in backward, a different one for another seed"""
+    from meant_amd import ops
+    for dtype in (torch.float32, torch.bfloat16):
+        x = (torch.rand(512, 768, device=dev) + 0.5).to(dtype).requires_grad_()
+        y = ops.dropout(x, 0.25, 99)
+        kept = y != 0
+        assert 0.74 < kept.float().mean().item() < 0.76
+        assert ((y[kept].float() - x.detach()[kept].float() / 0.75).abs() <= 2e-2 * x.detach()[kept].float()).all()
+        y.backward(torch.ones_like(y))
+        assert torch.equal(x.grad != 0, kept) and (x.grad[kept].float() - 1 / 0.75).abs().max().item() < 1e-2
+        assert not torch.equal(ops.dropout(x, 0.25, 100) != 0, kept)
+        assert ops.dropout(x, 0.0, 1) is x
 
 
 @pytest.mark.gpu

@@ -211,15 +211,22 @@ def test_mim_pretrainer_tiny(golden):
         assert abs(got - refn) <= 1e-4 * max(refn, 1e-6), (nm, got, refn)
 
 
-@pytest.mark.parametrize("fixture", ["timesformer_tiny", "timesformer_tiny_mask"])
+TS_CFG = {"timesformer_tiny": dict(dim=128, num_frames=3, num_classes=5, seed=8642),
+          "timesformer_tiny_mask": dict(dim=128, num_frames=3, num_classes=5, seed=8642),
+          "timesformer_tiny_shift": dict(dim=192, num_frames=4, num_classes=3, seed=8643, shift_tokens=True)}
+
+
+@pytest.mark.parametrize("fixture", list(TS_CFG))
 def test_timesformer_tiny(golden, fixture):
     """the oracle's divided space-time attention (cls token, frame + axial rotary, GEGLU; with and
     without the frame mask of :241-253) against the fork's TimeSformer (src/meant/timesformer_pytorch.py), tokens /
     logits / loss / gradients"""
     g = golden(fixture)
     torch.manual_seed(0)
-    m = O.TimeSformer(dim=128, num_frames=3, num_classes=5, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64).eval()
-    O.fill_weights_(m, 8642)
+    cfg = dict(TS_CFG[fixture])
+    seed = cfg.pop("seed")
+    m = O.TimeSformer(image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64, **cfg).eval()
+    O.fill_weights_(m, seed)
     mask = torch.from_numpy(g["mask"]) if "mask" in g.files else None
     x = m.meant_forward(torch.from_numpy(g["video"]), mask=mask)
     logits = m.to_out(x[:, 0])
