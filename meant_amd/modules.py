@@ -729,18 +729,19 @@ class TimeSformer(nn.Module):
     def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64,
                  attn_dropout=0., ff_dropout=0., rotary_emb=True, shift_tokens=False):
         super().__init__()
-        if not rotary_emb:
-            raise NotImplementedError("meant_amd.TimeSformer: rotary_emb=True (what the fork's models construct, "
-                                      "src/meant/meant_vision.py:130-162) is on the path; the learned-position variant is not")
+        self.use_rotary_emb = bool(rotary_emb)
         self.shift_tokens, self.attn_dropout, self.ff_dropout = bool(shift_tokens), float(attn_dropout), float(ff_dropout)
         assert image_size % patch_size == 0, "Image dimensions must be divisible by the patch size."
         self.heads, self.patch_size, self.dim_head, self.num_frames = heads, patch_size, dim_head, num_frames
         self.to_patch_embedding = Linear(channels * patch_size ** 2, dim)
         self.cls_token = nn.Parameter(torch.randn(1, dim))
-        self.frame_rot_emb = nn.Module()
-        self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
-        self.image_rot_emb = nn.Module()
-        self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
+        if rotary_emb:
+            self.frame_rot_emb = nn.Module()
+            self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
+            self.image_rot_emb = nn.Module()
+            self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
+        else:                                            # learned positions added to the tokens (:186, :220-221)
+            self.pos_emb = nn.Embedding(num_frames * (image_size // patch_size) ** 2 + 1, dim)
         wrap = (lambda fn: _TSPreTokenShift(num_frames, fn)) if shift_tokens else (lambda fn: fn)      # :196-199
         self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
                                                     _TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
@@ -761,16 +762,20 @@ class TimeSformer(nn.Module):
         n = hp * wp
         L = 1 + f * n
         with torch.no_grad():
-            inv = self.frame_rot_emb.inv_freqs.detach().float().cpu()
-            fr = torch.arange(f).float()[:, None] * inv[None, :]
-            fr = torch.cat((fr, fr), dim=-1)                                                 # [f, Dh] (src/utils/rotary.py:57-60)
-            sc = self.image_rot_emb.scales.detach().float().cpu()[None, :]
-            hs = torch.linspace(-1., 1., hp)[:, None] * sc * math.pi
-            ws = torch.linspace(-1., 1., wp)[:, None] * sc * math.pi
-            ang = torch.cat((hs[:, None, :].expand(hp, wp, -1), ws[None, :, :].expand(hp, wp, -1)), dim=-1).reshape(n, -1)
-            ang = ang.repeat_interleave(2, dim=-1)                                            # [n, Dh] (:46-48)
+            fr = ang = None
+            if self.use_rotary_emb:
+                inv = self.frame_rot_emb.inv_freqs.detach().float().cpu()
+                fr = torch.arange(f).float()[:, None] * inv[None, :]
+                fr = torch.cat((fr, fr), dim=-1)                                             # [f, Dh] (src/utils/rotary.py:57-60)
+                sc = self.image_rot_emb.scales.detach().float().cpu()[None, :]
+                hs = torch.linspace(-1., 1., hp)[:, None] * sc * math.pi
+                ws = torch.linspace(-1., 1., wp)[:, None] * sc * math.pi
+                ang = torch.cat((hs[:, None, :].expand(hp, wp, -1), ws[None, :, :].expand(hp, wp, -1)), dim=-1).reshape(n, -1)
+                ang = ang.repeat_interleave(2, dim=-1)                                        # [n, Dh] (:46-48)
 
             def tabs(a):
+                if a is None:
+                    return None
                 cos = torch.cat((torch.ones(1, a.shape[1]), a.cos())).contiguous().to(device)   # row 0: cls, not rotated
                 sin = torch.cat((torch.zeros(1, a.shape[1]), a.sin())).contiguous().to(device)
                 return (cos, sin, cos, sin)
@@ -811,6 +816,8 @@ class TimeSformer(nn.Module):
         tokens = self.to_patch_embedding(ops.patchify(video.reshape(b * f, c, hh, ww), p, dt)).view(b, f * n, -1)
         t_time, t_space, p_time, p_space, cat_fwd, cat_bwd = self._plan(b, f, hp, wp, video.device)
         x = ops.cls_concat(self.cls_token, tokens, cat_fwd, cat_bwd)
+        if not self.use_rotary_emb:
+            x = ops.add_rowvec(x, self.pos_emb.weight[:x.shape[1]].view(1, x.shape[1], -1))  # x += pos_emb(arange(L)), :220-221
         time_mask = cls_mask = None
         if mask is not None:
             m = mask.to(video.device).float()

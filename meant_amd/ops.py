@@ -1178,8 +1178,9 @@ class _DividedAttention(torch.autograd.Function):
         dt = _dt(qkv)
         q2 = qkv.view(b * L, D3)
         grouped = gather_rows(q2, idx_in)                                       # [b G S, 3 D]
-        qa, qb, ka, kb = tables
-        check(lib.meant_rotary_qk(_p(grouped), b * G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()), "rotary_qk")
+        if tables is not None:                                                  # rotary_emb=False: learned positions were added to x instead
+            qa, qb, ka, kb = tables
+            check(lib.meant_rotary_qk(_p(grouped), b * G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()), "rotary_qk")
         og = torch.empty((b * G * S, D), device=qkv.device, dtype=qkv.dtype)
         lse = torch.empty((b * G, H, S, 2), device=qkv.device, dtype=torch.float32)
         km = _c(group_mask.float()) if group_mask is not None else None         # [b G, S]
@@ -1205,9 +1206,9 @@ class _DividedAttention(torch.autograd.Function):
         dgrouped = torch.empty_like(grouped)
         wsb = lib.meant_attn_ws(b * G, S, H, Dh, dt)
         ws = torch.empty(max(wsb, 16), device=dout.device, dtype=torch.uint8)
-        qa, qb, ka, kb = ctx.tables
+        qa, qb, ka, kb = ctx.tables if ctx.tables is not None else (None, None, None, None)
         check(lib.meant_attn_bwd(_p(grouped), _p(og), _p(dog), _p(lse), _p(km), _p(dgrouped), b * G, S, H, Dh, scale, 0,
-                                 _p(qa), _p(qb), _p(ka), _p(kb), qa.shape[1], dt, _p(ws), wsb, _stream()), "attn_bwd")
+                                 _p(qa), _p(qb), _p(ka), _p(kb), qa.shape[1] if qa is not None else 0, dt, _p(ws), wsb, _stream()), "attn_bwd")
         dqkv = torch.empty_like(qkv)
         check(lib.meant_group_scatter(_p(dgrouped), _p(index), _p(dqkv), b, L, G, S, 3 * D, dt, _stream()), "group_scatter")
         check(lib.meant_attn_cls_bwd(_p(qkv), _p(out), L * D, _p(dout), L * D, _p(stats), _p(cm), _p(dqkv), b, L, H, Dh, scale, dt, _stream()),

@@ -359,6 +359,36 @@ def gen_timesformer_shift(R):
     save("timesformer_tiny_shift", **arrs)
 
 
+def gen_timesformer_posemb(R):
+    """rotary_emb=False: learned positional embedding added to the tokens (src/meant/timesformer_pytorch.py:186,220-221)"""
+    import types
+    from oracle.meant_oracle import fill_weights_
+    for name in ("src", "src.utils", "src.meant"):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name); pkg.__path__ = []; sys.modules[name] = pkg
+    _load("src.utils.rotary", f"{REF}/src/utils/rotary.py")
+    ref = _load("src.meant.timesformer_pytorch", f"{REF}/src/meant/timesformer_pytorch.py")
+    torch.manual_seed(0)
+    m = ref.TimeSformer(dim=128, num_frames=3, num_classes=5, image_size=32, patch_size=16, channels=4, depth=2, heads=2, dim_head=64,
+                        rotary_emb=False).eval()
+    fill_weights_(m, 8644)
+    r = np.random.RandomState(109)
+    video = r.standard_normal((2, 3, 4, 32, 32)).astype("float32")
+    x = m.meant_forward(torch.from_numpy(video))
+    logits = m.to_out(x[:, 0])
+    tgt = np.array([3, 1])
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(tgt)) + 0.01 * x.pow(2).mean()
+    loss.backward()
+    names, norms = grads_of(m)
+    params = dict(m.named_parameters())
+    arrs = dict(video=video, target=tgt, tokens=_np(x), logits=_np(logits), loss=np.array(loss.item(), dtype="float64"),
+                grad_names=np.array(names), grad_norms=norms)
+    for k in ["cls_token", "pos_emb.weight", "layers.0.0.fn.to_qkv.weight", "to_patch_embedding.bias"]:
+        g = params[k].grad
+        arrs["grad__" + k] = _np(g if g.numel() <= 4096 else g[:4])
+    save("timesformer_tiny_posemb", **arrs)
+
+
 def gen_timesformer_mask(R):
     """the same with a frame mask (src/meant/timesformer_pytorch.py:241-253: `mask` [b, f] bool hides whole frames from the
     time attention's keys and from the cls query; the space attention only masks the cls query): video 0 loses its last
@@ -394,7 +424,7 @@ def gen_timesformer_mask(R):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
         torch.set_num_threads(8)
-        {"mlm": gen_mlm, "mim": gen_mim, "timesformer": gen_timesformer, "timesformer_mask": gen_timesformer_mask, "timesformer_shift": gen_timesformer_shift}[sys.argv[2]](load_reference())
+        {"mlm": gen_mlm, "mim": gen_mim, "timesformer": gen_timesformer, "timesformer_mask": gen_timesformer_mask, "timesformer_shift": gen_timesformer_shift, "timesformer_posemb": gen_timesformer_posemb}[sys.argv[2]](load_reference())
     else:
         main()
         R_ = load_reference()
@@ -403,3 +433,4 @@ if __name__ == "__main__":
         gen_timesformer(R_)
         gen_timesformer_mask(R_)
         gen_timesformer_shift(R_)
+        gen_timesformer_posemb(R_)

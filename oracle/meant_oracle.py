@@ -551,15 +551,19 @@ class TimeSformer(nn.Module):
     linspace(-1, 1) along h then w, each angle repeated on a lane pair (:21-49); both rotate adjacent pairs."""
 
     def __init__(self, *, dim, num_frames, num_classes, image_size=224, patch_size=16, channels=3, depth=12, heads=8, dim_head=64,
-                 shift_tokens=False):
+                 shift_tokens=False, rotary_emb=True):
         super().__init__()
         self.heads, self.patch_size, self.dim_head = heads, patch_size, dim_head
+        self.use_rotary_emb = rotary_emb
         self.to_patch_embedding = nn.Linear(channels * patch_size ** 2, dim)
         self.cls_token = nn.Parameter(torch.randn(1, dim))
-        self.frame_rot_emb = nn.Module()
-        self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
-        self.image_rot_emb = nn.Module()
-        self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
+        if rotary_emb:
+            self.frame_rot_emb = nn.Module()
+            self.frame_rot_emb.register_buffer("inv_freqs", 1.0 / (10000 ** (torch.arange(0, dim_head, 2).float() / dim_head)))
+            self.image_rot_emb = nn.Module()
+            self.image_rot_emb.register_buffer("scales", torch.logspace(0., math.log(10 / 2) / math.log(2), dim_head // 4, base=2))
+        else:
+            self.pos_emb = nn.Embedding(num_frames * (image_size // patch_size) ** 2 + 1, dim)           # :186
         wrap = (lambda fn: _TSPreTokenShift(num_frames, fn)) if shift_tokens else (lambda fn: fn)      # :196-199
         self.layers = nn.ModuleList([nn.ModuleList([_TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
                                                     _TSPreNorm(dim, wrap(_TSAttention(dim, dim_head, heads))),
@@ -584,7 +588,12 @@ class TimeSformer(nn.Module):
         n = hp * wp
         tok = video.reshape(b, f, c, hp, p, wp, p).permute(0, 1, 3, 5, 4, 6, 2).reshape(b, f * n, p * p * c)   # (p1 p2 c)
         x = torch.cat((self.cls_token[None].expand(b, -1, -1), self.to_patch_embedding(tok)), dim=1)
-        frame_rot, image_rot = self.rotary_tables(f, hp, wp)
+        if self.use_rotary_emb:
+            frame_rot, image_rot = self.rotary_tables(f, hp, wp)
+        else:
+            x = x + self.pos_emb(torch.arange(x.shape[1]))                                         # :220-221
+            ident = (torch.zeros(1, 2), torch.ones(1, 2))                                            # sin 0, cos 1: no rotation
+            frame_rot = image_rot = ident
         frame_mask = cls_mask = None
         if mask is not None:
             one = torch.ones(b, 1, dtype=torch.bool)

@@ -329,7 +329,7 @@ def test_mim_pretrainer_golden(dev, golden, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("fixture", ["timesformer_tiny", "timesformer_tiny_mask", "timesformer_tiny_shift"])
+@pytest.mark.parametrize("fixture", ["timesformer_tiny", "timesformer_tiny_mask", "timesformer_tiny_shift", "timesformer_tiny_posemb"])
 def test_timesformer_golden(dev, golden, dtype, fixture):
     """divided space-time attention (time then space, cls token, frame + axial rotary, GEGLU; with and
     without the frame mask) against the fork's TimeSformer (fixtures from src/meant/timesformer_pytorch.py).  The whole

@@ -213,7 +213,8 @@ def test_mim_pretrainer_tiny(golden):
 
 TS_CFG = {"timesformer_tiny": dict(dim=128, num_frames=3, num_classes=5, seed=8642),
           "timesformer_tiny_mask": dict(dim=128, num_frames=3, num_classes=5, seed=8642),
-          "timesformer_tiny_shift": dict(dim=192, num_frames=4, num_classes=3, seed=8643, shift_tokens=True)}
+          "timesformer_tiny_shift": dict(dim=192, num_frames=4, num_classes=3, seed=8643, shift_tokens=True),
+          "timesformer_tiny_posemb": dict(dim=128, num_frames=3, num_classes=5, seed=8644, rotary_emb=False)}
 
 
 @pytest.mark.parametrize("fixture", list(TS_CFG))
