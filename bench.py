@@ -174,10 +174,10 @@ class GemmTimer:
 
     def traffic_per_launch(self):
         """HBM bytes per launch of the dominant kernel, averaged over the launches timed above, from the PMC table
-        in profiles/r01_nt256s_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+        in profiles/r02_nt256s_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
         corrections applied; measured on the plain epilogue) plus the algorithmic bytes of the extra epilogue
         operands (residual read / pre-activation write).  None if a launched shape is not in the table."""
-        path = os.path.join(ROOT, "profiles", "r01_nt256s_hbm_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r02_nt256s_hbm_traffic.json")
         if not os.path.exists(path):
             return None
         table = json.load(open(path))["shapes"]

@@ -5,6 +5,7 @@
 import csv, glob, json, sys, collections
 sys.path.insert(0, ".")
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+dram_dir = sys.argv[4] if len(sys.argv) > 4 else None      # optional third pass: TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum
 SHAPES = [(786432, 2304, 768), (786432, 768, 768), (786432, 768, 2304),
           (301056, 768, 1024), (301056, 2304, 768), (301056, 768, 768), (301056, 768, 2304)]
 
@@ -19,6 +20,8 @@ def per_dispatch(d, counter):
 
 fe, wr = per_dispatch(fetch_dir, "FETCH_SIZE"), per_dispatch(write_dir, "WRITE_SIZE")
 assert len(fe) == len(wr) == 3 * len(SHAPES), (len(fe), len(wr))
+rq = per_dispatch(dram_dir, "TCC_EA0_RDREQ_sum") if dram_dir else None
+rd = per_dispatch(dram_dir, "TCC_EA0_RDREQ_DRAM_sum") if dram_dir else None
 res = {}
 for i, (M, N, K) in enumerate(SHAPES):
     f = sum(fe[3 * i:3 * i + 3]) / 3 * 1024 * 2
@@ -26,6 +29,11 @@ for i, (M, N, K) in enumerate(SHAPES):
     alg = (M * K + N * K + M * N) * 2
     res[f"{M},{N},{K}"] = {"hbm_bytes": f + w, "fetch_bytes_corrected": f, "write_bytes": w, "algorithmic_bytes": alg,
                            "ratio": round((f + w) / alg, 3)}
+    if rq and rd and len(rq) == len(fe):
+        # share of the L2's read requests that the fabric sent on to DRAM (the rest were Infinity-Cache hits): FETCH_SIZE
+        # counts both (MI355X_MICROARCH.md, HBM section)
+        q, dd = sum(rq[3 * i:3 * i + 3]), sum(rd[3 * i:3 * i + 3])
+        res[f"{M},{N},{K}"]["read_requests_to_dram_share"] = round(dd / q, 3) if q else None
 json.dump({"kernel": "gemm_bf16_nt256s_kernel", "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
            "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)", "shapes": res},
           open(out, "w"), indent=1)
