@@ -136,9 +136,10 @@ class GemmTimer:
         # meant_rmsnorm_bwd(dy, x, scale, rinv, dx, dscale, rows, d, eps, p, seed, dres, gelu_pre, ...): read dy, x (+ dres, gelu_pre), write dx
         proxy.meant_rmsnorm_bwd = wrap("meant_rmsnorm_bwd", None, None, "rmsnorm_bwd",
                                        lambda a: (3.0 + (1 if a[11] else 0) + (1 if a[12] else 0)) * a[6] * a[7] * es)
-        # meant_rmsnorm_bwd_pooled(dy, dy_pooled, x, scale, rinv, dx, dscale, rows, d, group_rows, eps, p, seed, dres, dres_pooled, gelu_pre, ...)
+        # meant_rmsnorm_bwd_pooled(dy, dy_pooled, x, scale, rinv, dx, dscale, rows, d, group_rows, eps, p, seed, dres, dres_pooled, gelu_pre, ...):
+        # write dx; read x (unless formed from gelu_pre), dy / dres unless pooled, gelu_pre
         proxy.meant_rmsnorm_bwd_pooled = wrap("meant_rmsnorm_bwd_pooled", None, None, "rmsnorm_bwd_pooled",
-                                              lambda a: (2.0 + (0 if a[1] else 1) + (1 if (a[13] and not a[14]) else 0) + (1 if a[15] else 0)) * a[7] * a[8] * es)
+                                              lambda a: (1.0 + (1 if a[2] else 0) + (0 if a[1] else 1) + (1 if (a[13] and not a[14]) else 0) + (1 if a[15] else 0)) * a[7] * a[8] * es)
         ops.lib = proxy
 
     def others_summary(self):

@@ -104,6 +104,9 @@ int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const f
  * sequence.  meant_rmsnorm_fwd_pooled writes that mean to pooled[g, :] (float [rows / group_rows, d]; ordered sums, bit-reproducible):
  *   pool_input == 0: of y = dropout(RMSNorm(x)) -- y is NOT written (pass NULL);
  *   pool_input != 0: of x, the residual operand -- y is written as usual.
+ * gelu_input != 0 (with pool_input == 0): x is the PRE-activation h of the Linear + GELU in front of the norm
+ * (meant/meant.py:63-64,106-107); gelu(h) is formed on load, so the activation tensor is never stored.  The backward
+ * then takes x == NULL and h as gelu_pre.
  * meant_rmsnorm_bwd_pooled is meant_rmsnorm_bwd with dy (dy_pooled != 0) and / or dres (dres_pooled != 0) given as the
  * float [groups, d] gradient of the pooled features: row r receives g[r / group_rows] / group_rows, no [rows, d]
  * broadcast is materialised.  Supported where meant_rmsnorm_pooled_ok(rows, d, group_rows) != 0 (the packed widths,
@@ -111,8 +114,8 @@ int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const f
  * otherwise. */
 int meant_rmsnorm_pooled_ok(int64_t rows, int64_t d, int64_t group_rows);
 int meant_rmsnorm_fwd_pooled(const void* x, const float* scale, void* y, float* rinv, float* pooled, int64_t rows,
-                             int64_t d, int64_t group_rows, int pool_input, float eps, float drop_p, uint64_t seed,
-                             int dtype, void* stream);
+                             int64_t d, int64_t group_rows, int pool_input, int gelu_input, float eps, float drop_p,
+                             uint64_t seed, int dtype, void* stream);
 int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv,
                              void* dx, float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps,
                              float drop_p, uint64_t seed, const void* dres, int dres_pooled, const void* gelu_pre,

@@ -27,7 +27,7 @@ SIGNATURES = {
     "meant_rmsnorm_bwd_ws": (_sz, [_i64, _i64]),
     "meant_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _u64, _p, _p, _i, _p, _sz, _p]),
     "meant_rmsnorm_pooled_ok": (_i, [_i64, _i64, _i64]),
-    "meant_rmsnorm_fwd_pooled": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _f, _f, _u64, _i, _p]),
+    "meant_rmsnorm_fwd_pooled": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _f, _f, _u64, _i, _p]),
     "meant_rmsnorm_bwd_pooled": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _u64, _p, _i, _p, _i, _p, _sz, _p]),
     "meant_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p]),
     "meant_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _sz, _p]),

@@ -222,7 +222,10 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const 
 // operand).  A workgroup owns whole groups: its four waves split a group's rows into four contiguous runs, keep column
 // sums in registers, and combine them through LDS in a fixed order -- no atomics, so the forward stays bit-reproducible.
 // group_rows is a multiple of R (a wave's step never straddles a group).
-template <typename T, int C, int POOL>
+// GELU_IN: x holds the PRE-activation h of the Linear + GELU that feeds this norm (meant/meant.py:63-64, :106-107); the
+// activation gelu(h), rounded to the storage type as the GEMM epilogue would have stored it, is formed on load, so that
+// tensor is never written or read.
+template <typename T, int C, int POOL, bool GELU_IN>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                                            T* __restrict__ y, float* __restrict__ rinv_out,
                                                                            int64_t ngroups, int d, int R, float eps, float drop_p,
@@ -258,6 +261,12 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
       float ss[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) v[c] = load8<T>(xr + (lane + 64 * c) * 8);
+      if (GELU_IN) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[c].set(i, gelu_erf_fast(v[c].get(i)));
+      }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         ss[c] = 0.f;
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 
 // BC bit 0: dy is the gradient of the POOLED features, float [groups, d]: row r receives dy_g[r / group_rows] / group_rows
 // (the backward of POOL = 1 above -- no [tokens, d] broadcast is ever materialised); bit 1: the same for dres (POOL = 2).
+// BC bit 2: x is not stored at all -- it is gelu(gelu_pre), formed on load (the forward's GELU_IN)
 template <typename T, int C, int BC>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                            const float* __restrict__ scale,
@@ -349,12 +359,15 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t o = off + (lane + 64 * c) * 8;
-      xv[c] = load8<T>(x + o);
+      if (gelu_pre) pv[c] = load8<T>(gelu_pre + o);
+      if (BC & 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_erf_fast(pv[c].get(i)));
+      } else xv[c] = load8<T>(x + o);
       if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
       else dv[c] = load8<T>(dy + o);
       if (BC & 2) rvg[c] = load8<float>(reinterpret_cast<const float*>(dres) + pg * d + col[c]);
       else if (dres) rv[c] = load8<T>(dres + o);
-      if (gelu_pre) pv[c] = load8<T>(gelu_pre + o);
     }
     float rr[C], cd[C], gd[C][8];
 #pragma unroll
@@ -627,9 +640,10 @@ extern "C" int meant_rmsnorm_pooled_ok(int64_t rows, int64_t d, int64_t group_ro
 }
 
 extern "C" int meant_rmsnorm_fwd_pooled(const void* x, const float* scale, void* y, float* rinv, float* pooled, int64_t rows, int64_t d,
-                                        int64_t group_rows, int pool_input, float eps, float drop_p, uint64_t seed, int dtype,
-                                        void* stream) {
+                                        int64_t group_rows, int pool_input, int gelu_input, float eps, float drop_p, uint64_t seed,
+                                        int dtype, void* stream) {
   MEANT_REQUIRE(x && scale && rinv && pooled && (y || !pool_input), MEANT_ERR_ARG, "rmsnorm_fwd_pooled: null pointer");
+  MEANT_REQUIRE(!(pool_input && gelu_input), MEANT_ERR_UNSUPPORTED, "rmsnorm_fwd_pooled: gelu_input goes with pool_input == 0");
   MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows), MEANT_ERR_UNSUPPORTED,
                 "rmsnorm_fwd_pooled: rows=%lld d=%lld group_rows=%lld is not a packed shape (see meant_rmsnorm_pooled_ok)", (long long)rows,
                 (long long)d, (long long)group_rows);
@@ -639,11 +653,14 @@ extern "C" int meant_rmsnorm_fwd_pooled(const void* x, const float* scale, void*
   norm_packing(rows, d, R, C);
   const int64_t ngroups = rows / group_rows;
   const int nb = (int)(ngroups < NORM_PACKED_BLOCKS ? ngroups : NORM_PACKED_BLOCKS);
-#define LAUNCH_FWDP(CC, PP)                                                                                                   \
-    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_fwd_pooled_kernel<T, CC, PP>), dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+#define LAUNCH_FWDP(CC, PP, GG)                                                                                               \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_fwd_pooled_kernel<T, CC, PP, GG>), dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
                                                 (const T*)x, scale, (T*)y, rinv, ngroups, (int)d, R, eps, drop_p, seed, pooled, (int)group_rows))
-  if (pool_input) { if (C == 1) LAUNCH_FWDP(1, 2); else if (C == 2) LAUNCH_FWDP(2, 2); else LAUNCH_FWDP(3, 2); }
-  else { if (C == 1) LAUNCH_FWDP(1, 1); else if (C == 2) LAUNCH_FWDP(2, 1); else LAUNCH_FWDP(3, 1); }
+#define LAUNCH_FWDP_C(PP, GG) { if (C == 1) LAUNCH_FWDP(1, PP, GG); else if (C == 2) LAUNCH_FWDP(2, PP, GG); else LAUNCH_FWDP(3, PP, GG); }
+  if (pool_input) LAUNCH_FWDP_C(2, false)
+  else if (gelu_input) LAUNCH_FWDP_C(1, true)
+  else LAUNCH_FWDP_C(1, false)
+#undef LAUNCH_FWDP_C
 #undef LAUNCH_FWDP
   MEANT_LAUNCH_CHECK("rmsnorm_fwd_pooled");
   return MEANT_OK;
@@ -653,20 +670,21 @@ extern "C" int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const voi
                                         float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps, float drop_p, uint64_t seed,
                                         const void* dres, int dres_pooled, const void* gelu_pre, int dtype, void* workspace,
                                         size_t workspace_bytes, void* stream) {
-  MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd_pooled: null pointer");
+  MEANT_REQUIRE(dy && (x || gelu_pre) && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_bwd_pooled: null pointer");
   MEANT_REQUIRE((dy_pooled || dres_pooled) && (!dres_pooled || dres), MEANT_ERR_ARG, "rmsnorm_bwd_pooled: nothing pooled (use meant_rmsnorm_bwd)");
   MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows) && rows < 2147483647LL, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_pooled: not a packed shape");
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_pooled: workspace too small");
   int R, C;
   norm_packing(rows, d, R, C);
   const int nbp = packed_blocks(rows / R);
-  const int bc = (dy_pooled ? 1 : 0) | (dres_pooled ? 2 : 0);
+  const int bc = (dy_pooled ? 1 : 0) | (dres_pooled ? 2 : 0) | (x ? 0 : 4);
+  MEANT_REQUIRE(bc == 1 || bc == 2 || bc == 3 || bc == 5, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_pooled: unsupported combination");
 #define LAUNCH_BWDP(CC, BB)                                                                                                   \
     DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, BB>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
                                                 (const T*)dy, (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, R, eps,    \
                                                 drop_p, seed, (const T*)dres, (const T*)gelu_pre, (int)group_rows))
 #define LAUNCH_BWDP_C(BB) { if (C == 1) LAUNCH_BWDP(1, BB); else if (C == 2) LAUNCH_BWDP(2, BB); else LAUNCH_BWDP(3, BB); }
-  if (bc == 1) LAUNCH_BWDP_C(1) else if (bc == 2) LAUNCH_BWDP_C(2) else LAUNCH_BWDP_C(3)
+  if (bc == 1) LAUNCH_BWDP_C(1) else if (bc == 2) LAUNCH_BWDP_C(2) else if (bc == 3) LAUNCH_BWDP_C(3) else LAUNCH_BWDP_C(5)
 #undef LAUNCH_BWDP_C
 #undef LAUNCH_BWDP
   MEANT_LAUNCH_CHECK("rmsnorm_bwd_pooled");

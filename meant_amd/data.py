@@ -101,6 +101,8 @@ class DeviceBatchLoader:
     def close(self):
         """undo the in-place page-locking of the source arrays (also done on garbage collection)"""
         if any(self._registered):
+            if self._stream is not None:
+                self._stream.synchronize()               # rows still being DMA'd out of the page-locked arrays must have left them
             rt = torch.cuda.cudart()
             for i, a in enumerate(self.arrays):
                 if self._registered[i]:
@@ -186,21 +188,28 @@ class DeviceBatchLoader:
 
         if nb:
             produce(0, 0)
-        for b in range(nb):
-            k = b & 1
+        try:
+            for b in range(nb):
+                k = b & 1
+                if pending is not None:
+                    pending.join()
+                    pending = None
+                if self.on_gpu:
+                    torch.cuda.current_stream(self.device).wait_event(self._ready[k])
+                if b + 1 < nb:                            # batch b+1 is gathered and sent while the caller runs step b
+                    pending = threading.Thread(target=produce, args=(k ^ 1, b + 1), daemon=True)
+                    pending.start()
+                yield tuple(self._dev[k])
+                if self.on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    consumed[k] = ev
+            self.epoch += 1
+        finally:
+            # also when the caller leaves the loop early (break, exception, the generator being collected): the producer
+            # thread must not outlive the iteration -- it copies into staging buffers that die with this object -- and its
+            # copies must have left the copy stream before those buffers can be freed
             if pending is not None:
                 pending.join()
-                pending = None
             if self.on_gpu:
-                torch.cuda.current_stream(self.device).wait_event(self._ready[k])
-            if b + 1 < nb:                                # batch b+1 is gathered and sent while the caller runs step b
-                pending = threading.Thread(target=produce, args=(k ^ 1, b + 1), daemon=True)
-                pending.start()
-            yield tuple(self._dev[k])
-            if self.on_gpu:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                consumed[k] = ev
-        if pending is not None:
-            pending.join()
-        self.epoch += 1
+                self._stream.synchronize()

@@ -302,7 +302,7 @@ class _RMSNormForkPooled(torch.autograd.Function):
         rinv = torch.empty(G * S, device=x.device, dtype=torch.float32)
         xm = torch.empty((G, d), device=x.device, dtype=torch.float32)
         sc = _c(scale.detach().float())
-        check(lib.meant_rmsnorm_fwd_pooled(_p(x), _p(sc), _p(y), _p(rinv), _p(xm), G * S, d, S, 1, eps, 0.0, 0, _dt(x), _stream()),
+        check(lib.meant_rmsnorm_fwd_pooled(_p(x), _p(sc), _p(y), _p(rinv), _p(xm), G * S, d, S, 1, 0, eps, 0.0, 0, _dt(x), _stream()),
               "rmsnorm_fwd_pooled")
         ctx.save_for_backward(x, sc, rinv)
         ctx.eps, ctx.S = eps, S
@@ -319,29 +319,38 @@ class _RMSNormForkPooled(torch.autograd.Function):
 
 
 class _GeluRMSNormPooled(torch.autograd.Function):
-    """mean over each sequence of dropout(RMSNorm(gelu(pre))) given a = gelu(pre) and pre (see _GeluRMSNorm): float [G, d].
-    The normalised tokens themselves are never written, and the backward reads the [G, d] gradient of the mean."""
+    """mean over each sequence of dropout(RMSNorm(gelu(pre))) given the pre-activation `pre` [G, S, d] alone: float [G, d].
+    Neither gelu(pre) nor the normalised tokens are ever written -- both are formed on load, forward and backward --, and
+    the backward reads the [G, d] gradient of the mean."""
 
     @staticmethod
-    def forward(ctx, a, pre, scale, eps, drop_p, seed):
-        _need_gpu(a, pre, scale)
-        a = _c(a)
-        G, S, d = a.shape
-        rinv = torch.empty(G * S, device=a.device, dtype=torch.float32)
-        hm = torch.empty((G, d), device=a.device, dtype=torch.float32)
+    def forward(ctx, pre, scale, eps, drop_p, seed):
+        _need_gpu(pre, scale)
+        pre = _c(pre)
+        G, S, d = pre.shape
+        rinv = torch.empty(G * S, device=pre.device, dtype=torch.float32)
+        hm = torch.empty((G, d), device=pre.device, dtype=torch.float32)
         sc = _c(scale.detach().float())
-        check(lib.meant_rmsnorm_fwd_pooled(_p(a), _p(sc), None, _p(rinv), _p(hm), G * S, d, S, 0, eps, drop_p, seed, _dt(a), _stream()),
+        check(lib.meant_rmsnorm_fwd_pooled(_p(pre), _p(sc), None, _p(rinv), _p(hm), G * S, d, S, 0, 1, eps, drop_p, seed, _dt(pre), _stream()),
               "rmsnorm_fwd_pooled")
-        ctx.save_for_backward(a, _c(pre), sc, rinv)
+        ctx.save_for_backward(pre, sc, rinv)
         ctx.args, ctx.S = (eps, drop_p, seed), S
         return hm
 
     @staticmethod
     def backward(ctx, dhm):
-        a, pre, sc, rinv = ctx.saved_tensors
+        pre, sc, rinv = ctx.saved_tensors
         eps, drop_p, seed = ctx.args
-        dpre, dscale = _rmsnorm_bwd_pooled_raw(_c(dhm.float()), True, a, sc, rinv, ctx.S, eps, drop_p, seed, None, False, pre)
-        return None, dpre, dscale, None, None, None
+        d = pre.shape[-1]
+        rows = pre.numel() // d
+        dpre = torch.empty_like(pre)
+        dscale = torch.empty(d, device=pre.device, dtype=torch.float32)
+        wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
+        ws = torch.empty(wsb, device=pre.device, dtype=torch.uint8)
+        dh = _c(dhm.float())
+        check(lib.meant_rmsnorm_bwd_pooled(_p(dh), 1, None, _p(sc), _p(rinv), _p(dpre), _p(dscale), rows, d, ctx.S, eps, drop_p, seed,
+                                           None, 0, _p(pre), _dt(pre), _p(ws), wsb, _stream()), "rmsnorm_bwd_pooled")
+        return dpre, dscale, None, None, None
 
 
 def rmsnorm_fork_pooled(x, scale, eps=1e-8):
@@ -349,9 +358,9 @@ def rmsnorm_fork_pooled(x, scale, eps=1e-8):
 
 
 def linear_gelu_rmsnorm_pooled(x, weight, bias, scale, eps=1e-8, drop_p=0.0, seed=0):
-    """mean_s(dropout(RMSNorm(gelu(x W^T + b)))) -> float [G, d]"""
-    a, pre = _LinearPre.apply(x, weight, bias)
-    return _GeluRMSNormPooled.apply(a, pre, scale, float(eps), float(drop_p), int(seed))
+    """mean_s(dropout(RMSNorm(gelu(x W^T + b)))) -> float [G, d]; the GEMM stores the pre-activation only"""
+    pre = linear(x, weight, bias)
+    return _GeluRMSNormPooled.apply(pre, scale, float(eps), float(drop_p), int(seed))
 
 
 class _LayerNorm(torch.autograd.Function):
