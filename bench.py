@@ -445,7 +445,10 @@ def main():
                     "traffic": None if traffic is None else round(traffic),
                     "launches_timed": n, "avg_launch_ms": round(gt / max(n, 1) * 1e3, 4),
                     "avg_launch_gflop": round(gf / max(n, 1) / 1e9, 2),
-                    "whole_step_mfma_frac": round(sps / world * flops_per_sample_executed(E) / (PEAK_BF16_TFLOPS * 1e12), 4)}
+                    "whole_step_mfma_frac": round(sps / world * flops_per_sample_executed(E) / (PEAK_BF16_TFLOPS * 1e12), 4),
+                    # the same step priced at the reference graph's FLOPs (what a literal evaluation of the module list would
+                    # execute; the pooled last Linear of each stack skips part of it, see DESIGN.md section 6 "Pooled tail")
+                    "whole_step_mfma_frac_reference_graph": round(sps / world * flops_per_sample(E) / (PEAK_BF16_TFLOPS * 1e12), 4)}
         if iso_steps:
             n2, gf2, gt2 = timer.summary(overlapped_recs)
             roofline["timed_in"] = f"{iso_steps} extra single-stream steps after the timed region"

@@ -204,6 +204,12 @@ int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float*
  * elements, W % 8 == 0.  (Regrouping, its inverse for the outputs, and the cls-token concatenation of :211-213.) */
 int meant_gather_rows(const void* src, const int32_t* idx, const void* fill, void* dst, int64_t n, int64_t W, int dtype,
                       void* stream);
+/* The regrouping gather of a packed q|k|v buffer (rows of 3 * H * Dh) with the rotary map applied on the way: row r of dst is
+ * row idx[r] of src (zeros for idx[r] < 0), its q and k heads rotated by the tables' row r % S exactly as meant_rotary_qk
+ * (transpose = 0) would rotate them in place afterwards (same arithmetic, one rounding); v is copied.
+ * (timesformer_pytorch.py:124-131: rearrange, then rot_emb.rotate_queries_and_keys.) */
+int meant_gather_rows_rot(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t S, int H, int Dh, int R,
+                          const float* qa, const float* qb, const float* ka, const float* kb, int dtype, void* stream);
 /* backward of a regrouping gather with index int32 [G, S] into the L rows of each of B sequences, whose column 0 is
  * the same (cls) row in every group and whose other entries are a permutation of the remaining rows: dsrc [B, L, W]
  * is written completely -- dsrc[b, index[g, s]] = ddst[b, g, s] for s >= 1, dsrc[b, index[0, 0]] = sum_g ddst[b, g, 0]. */

@@ -47,6 +47,7 @@ SIGNATURES = {
     "meant_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "meant_qkv_proj_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "meant_gather_rows": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _p]),
+    "meant_gather_rows_rot": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "meant_group_scatter": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p]),
     "meant_attn_cls_fwd": (_i, [_p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _f, _i, _p]),
     "meant_attn_cls_bwd": (_i, [_p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _p]),

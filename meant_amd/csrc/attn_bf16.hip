@@ -1110,6 +1110,7 @@ static int attn_bf16_check(const char* name, int64_t G, int64_t S, int H, int Dh
 int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh, float scale,
                   int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!native_dh(Dh)) return attn_bf16_generic(false, qkv, nullptr, nullptr, o, lse, key_mask, nullptr, G, S, H, Dh, scale, causal, ws, ws_bytes, stream);
+  if (attn_short_ok(S, Dh)) return attn_short_fwd(qkv, o, lse, key_mask, G, S, H, Dh, scale, causal, stream);
   int rc = attn_bf16_check("attn_fwd", G, S, H, Dh);
   if (rc) return rc;
   MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o), MEANT_ERR_ARG, "attn_fwd: 16-byte alignment");
@@ -1155,6 +1156,8 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     if (rcg || !rot.qa) return rcg;
     return meant_rotary_qk(dqkv, G * S, S, H, Dh, rot.R, rot.qa, rot.qb, rot.ka, rot.kb, 1, MEANT_BF16, stream);
   }
+  if (attn_short_ok(S, Dh) && (!rot.qa || (rot.R % 8 == 0 && rot.R <= DH)))
+    return attn_short_bwd(qkv, dout, lse, key_mask, dqkv, G, S, H, Dh, scale, causal, rot, stream);
   MEANT_REQUIRE(!rot.qa || (rot.R % 8 == 0 && rot.R <= DH), MEANT_ERR_UNSUPPORTED, "attn_bwd: rotary dim must be a multiple of 8 and <= 64");
   int rc = attn_bf16_check("attn_bwd", G, S, H, Dh);
   if (rc) return rc;

@@ -78,6 +78,8 @@ const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"deterministic", "MEANT_DETERMINISTIC", 0},   // 1: parameter gradients are bit-reproducible (ordered reductions, no float atomics)
     {"nt_qkv_split", "MEANT_NT_QKV_SPLIT", 1},
     {"nt_grid_cap", "MEANT_NT_GRID_CAP", 0},       // tests: cap the streaming GEMM's grid (0 = one workgroup per CU)
+    {"attn_short", "MEANT_ATTN_SHORT", 1},         // 0: sequences of <= 16 tokens take the tiled flash kernels instead of attn_short.hip
+    {"nt_ragged", "MEANT_NT_RAGGED", 1},           // 0: ragged M as streaming head + 128 x 128 tail launch instead of the overlapped last row tile
 };
 std::atomic<int> g_opt[MEANT_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -123,7 +125,7 @@ namespace {
 const char* const k_routes[MEANT_ROUTE_COUNT] = {
     "nt128", "nt256", "nt256s", "nt256s_rot", "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32",
     "attn_fwd", "attn_fwd_d128", "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96",
-    "attn_generic", "attn_cls",
+    "attn_generic", "attn_cls", "attn_short", "nt_overlap",
 };
 std::atomic<long long> g_route[MEANT_ROUTE_COUNT];
 }  // namespace

@@ -36,6 +36,44 @@ __global__ __launch_bounds__(DIV_THREADS) void gather_rows_kernel(const T* __res
   }
 }
 
+// the regrouping gather of a packed q|k|v buffer with the rotary map applied on the way (row r sits at position r % S of its
+// group): one pass instead of gather + in-place rotary.  Same arithmetic as rotary_kernel (elementwise.hip): fp32 on the stored
+// values, one rounding, pairs (2j, 2j+1), columns >= R of a head and the v third copied.
+template <typename T>
+__global__ __launch_bounds__(DIV_THREADS) void gather_rows_rot_kernel(const T* __restrict__ src, const int* __restrict__ idx, T* __restrict__ dst, int64_t n,
+                                                                       int S, int HD, int Dh, int R, const float* __restrict__ qa,
+                                                                       const float* __restrict__ qb, const float* __restrict__ ka,
+                                                                       const float* __restrict__ kb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W = 3 * HD, nch = W >> 3;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+    const int id = idx[r];
+    const int pos = (int)(r % S);
+    for (int ch = lane; ch < nch; ch += 64) {
+      Vec8<T> v;
+      if (id >= 0) v = load8<T>(src + (int64_t)id * W + ch * 8);
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v.set(k, 0.f);
+      }
+      const int col = ch * 8, which = col / HD, dh = (col - which * HD) % Dh;
+      if (which < 2 && dh < R && id >= 0) {            // R % 8 == 0: a chunk is rotated as a whole or not at all
+        const float* A = (which ? ka : qa) + (int64_t)pos * R + dh;
+        const float* B = (which ? kb : qb) + (int64_t)pos * R + dh;
+        Vec8<T> o;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const float t0 = v.get(k), t1 = v.get(k + 1);
+          o.set(k, t0 * A[k] - t1 * B[k]);
+          o.set(k + 1, t1 * A[k + 1] + t0 * B[k + 1]);
+        }
+        v = o;
+      }
+      store8<T>(dst + r * W + ch * 8, v);
+    }
+  }
+}
+
 // rows s >= 1 of every group: dsrc[b, index[g, s], :] = ddst[b, g, s, :]
 template <typename T>
 __global__ __launch_bounds__(DIV_THREADS) void group_scatter_rows_kernel(const T* __restrict__ ddst, const int* __restrict__ index, T* __restrict__ dsrc,
@@ -267,6 +305,19 @@ extern "C" int meant_gather_rows(const void* src, const int32_t* idx, const void
   DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(rows_blocks(n)), dim3(DIV_THREADS), 0, (hipStream_t)stream, (const T*)src, idx,
                                               (const T*)fill, (T*)dst, n, (int)W));
   MEANT_LAUNCH_CHECK("gather_rows");
+  return MEANT_OK;
+}
+
+extern "C" int meant_gather_rows_rot(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t S, int H, int Dh, int R, const float* qa,
+                                     const float* qb, const float* ka, const float* kb, int dtype, void* stream) {
+  DIV_REQ(src && idx && dst && n > 0 && S > 0 && H > 0 && Dh > 0 && Dh % 8 == 0 && R >= 0 && R <= Dh && R % 8 == 0 && (int64_t)H * Dh * 3 < (1LL << 30),
+          "gather_rows_rot: bad argument (Dh and the rotary dim must be multiples of 8, R <= Dh)");
+  DIV_REQ(R == 0 || (qa && qb && ka && kb), "gather_rows_rot: null rotary table");
+  DIV_REQ(meant_aligned16(src) && meant_aligned16(dst) && (R == 0 || (meant_aligned16(qa) && meant_aligned16(qb) && meant_aligned16(ka) && meant_aligned16(kb))),
+          "gather_rows_rot: 16-byte alignment");
+  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_rows_rot_kernel<T>, dim3(rows_blocks(n)), dim3(DIV_THREADS), 0, (hipStream_t)stream, (const T*)src, idx,
+                                              (T*)dst, n, (int)S, H * Dh, Dh, R, qa, qb, ka, kb));
+  MEANT_LAUNCH_CHECK("gather_rows_rot");
   return MEANT_OK;
 }
 

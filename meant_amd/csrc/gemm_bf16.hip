@@ -443,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
     const int tm = t / ntn, tn = t - tm * ntn;
     m0 = (int64_t)tm * B2;
+    m0 = m0 + B2 <= a.M ? m0 : a.M - B2;               // ragged M: the last row tile is moved up to END at row M (see the launcher)
     n0 = (int64_t)tn * B2;
     pa = a.A + m0 * a.lda;
     pb = a.B + n0 * a.ldb;
@@ -1024,11 +1025,23 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
     MEANT_REQUIRE(ntm2 * ntn2 < 2147483647LL, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: grid too large");
     // option nt_stream = 0 forces the one-tile-per-workgroup kernel (A/B measurements)
     const bool stream_ok = meant_opt(MEANT_OPT_NT_STREAM) != 0;
-    // Ragged M: the streaming kernel takes the first floor(M / 256) * 256 rows, the remaining < 256 rows go to the
-    // 128 x 128 kernel as a second launch (row-local epilogues only: the rotary epilogue indexes its tables by the
+    // Ragged M, option nt_ragged = 1 (default): the streaming kernel takes all of it; its last row tile is moved up so that it
+    // ENDS at row M and recomputes up to 255 rows of its neighbour.  Every element of C is a function of its own row of A
+    // and column of W with a fixed K order, so both tiles store identical bits (no cost in the K-loop, no second launch:
+    // the 32 trailing rows of the TimeSformer's 75 296 tokens cost 12 extra launches of 13-97 us per layer as a split).
+    // Needs an out-of-place epilogue: a residual (or A) that aliases C would be read after the neighbour's store.
+    const auto overlaps = [](const void* p, int64_t ld, const void* q, int64_t ldq, int64_t rows) {
+      const char *p0 = (const char*)p, *q0 = (const char*)q;
+      return p && q && p0 < q0 + rows * ldq * 2 && q0 < p0 + rows * ld * 2;
+    };
+    const bool ragged_overlap = stream_ok && meant_opt(MEANT_OPT_NT_RAGGED) != 0 && a.M % B2 != 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 &&
+                                (!a.residual || (a.ldr & 7) == 0) && !overlaps(a.C, a.ldc, a.residual, a.ldr, a.M) &&
+                                !overlaps(a.C, a.ldc, a.A, a.lda, a.M) && (!a.preact || !overlaps(a.preact, a.ldc, a.A, a.lda, a.M));
+    // nt_ragged = 0 (or aliasing operands): the streaming kernel takes the first floor(M / 256) * 256 rows, the remaining < 256 rows go
+    // to the 128 x 128 kernel as a second launch (row-local epilogues only: the rotary epilogue indexes its tables by the
     // absolute row, so it splits only where the boundary is a multiple of the sequence length).
     const int64_t m_full = (a.M / B2) * B2;
-    if (stream_ok && m_full >= 1024 && m_full != a.M && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
+    if (!ragged_overlap && stream_ok && m_full >= 1024 && m_full != a.M && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
         (!a.rot_qa || m_full % a.rot_S == 0)) {
       GemmBf16Args head = a, tail = a;
       head.M = m_full;
@@ -1041,7 +1054,8 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       const int rc = gemm_bf16_nt_launch(head, stream);
       return rc ? rc : gemm_bf16_nt_launch(tail, stream);
     }
-    if (stream_ok && a.M % B2 == 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
+    if (stream_ok && (a.M % B2 == 0 || ragged_overlap) && a.K >= 2 * BK && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0)) {
+      if (ragged_overlap) meant_route_hit(ROUTE_NT_OVERLAP);
       int ncu = meant_num_cus() & ~7;
       const int cap = meant_opt(MEANT_OPT_NT_GRID_CAP) & ~7;     // tests: fewer workgroups => more tiles each, dry XCDs steal
       if (cap >= 8 && cap < ncu) ncu = cap;

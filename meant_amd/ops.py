@@ -1186,10 +1186,13 @@ class _DividedAttention(torch.autograd.Function):
         G, S = index.shape
         dt = _dt(qkv)
         q2 = qkv.view(b * L, D3)
-        grouped = gather_rows(q2, idx_in)                                       # [b G S, 3 D]
-        if tables is not None:                                                  # rotary_emb=False: learned positions were added to x instead
+        if tables is not None:                                                  # regrouped and rotated in one pass: [b G S, 3 D]
             qa, qb, ka, kb = tables
-            check(lib.meant_rotary_qk(_p(grouped), b * G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()), "rotary_qk")
+            grouped = torch.empty((b * G * S, D3), device=qkv.device, dtype=qkv.dtype)
+            check(lib.meant_gather_rows_rot(_p(q2), _p(idx_in), _p(grouped), b * G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb),
+                                            dt, _stream()), "gather_rows_rot")
+        else:                                                                   # rotary_emb=False: learned positions were added to x instead
+            grouped = gather_rows(q2, idx_in)
         og = torch.empty((b * G * S, D), device=qkv.device, dtype=qkv.dtype)
         lse = torch.empty((b * G, H, S, 2), device=qkv.device, dtype=torch.float32)
         km = _c(group_mask.float()) if group_mask is not None else None         # [b G, S]

@@ -104,12 +104,45 @@ def test_streaming_linear_few_workgroups_and_steals(L, dev, epi):
     assert stolen >= 2 * (432 - 64) * 3 // 4, f"only {stolen} tiles went through the steal path"
 
 
+@pytest.mark.parametrize("ragged", [1, 0], ids=["overlap", "split"])
 @pytest.mark.parametrize("dynamic", [1, 0], ids=["dyn", "fixed"])
 @pytest.mark.parametrize("M_,epi", [(33025, "none"), (33024 + 100, "residual"), (33024 + 255, "gelu")])
-def test_streaming_linear_ragged_rows(L, dev, M_, epi, dynamic):
-    """M not a multiple of 256: head (129 row tiles) on the streaming kernel, the < 256 trailing rows on the 128 x 128 kernel"""
-    r = _linear_case(L, dev, M_, 768, 768, epi, dynamic, 0)
-    assert r["nt_split"] == 1 and r["nt256s"] == 1 and r["nt128"] == 1, r
+def test_streaming_linear_ragged_rows(L, dev, M_, epi, dynamic, ragged):
+    """M not a multiple of 256.  Default (nt_ragged = 1): all 130 row tiles on the streaming kernel, the last one moved up to end at
+    row M (it recomputes rows of its neighbour bit-identically).  nt_ragged = 0 (what aliasing operands fall back to): head (129
+    row tiles) on the streaming kernel, the < 256 trailing rows on the 128 x 128 kernel."""
+    L.set_option("nt_ragged", ragged)
+    try:
+        L.route_reset()
+        r = _linear_case(L, dev, M_, 768, 768, epi, dynamic, 0)
+        ov = L.route_count("nt_overlap")
+    finally:
+        L.set_option("nt_ragged", 1)
+    if ragged:
+        assert r["nt_split"] == 0 and r["nt256s"] == 1 and r["nt128"] == 0 and ov >= 1, (r, ov)
+    else:
+        assert r["nt_split"] == 1 and r["nt256s"] == 1 and r["nt128"] == 1 and ov == 0, (r, ov)
+
+
+def test_ragged_rows_are_bit_identical_between_the_two_schemes(L, dev):
+    """the overlapped last tile and the head + tail split compute every element from the same operands in the same K order"""
+    import meant_amd.ops as ops
+    from meant_amd._lib import EPI_GELU
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.standard_normal((33024 + 77, 768)).astype("float32")).to(dev).to(BF)
+    w = torch.from_numpy((rs.standard_normal((768, 768)) * 0.05).astype("float32")).to(dev)
+    b = torch.from_numpy(rs.standard_normal(768).astype("float32")).to(dev)
+    with torch.no_grad():
+        y1 = ops.linear(x, w, b, None, EPI_GELU)
+        L.set_option("nt_ragged", 0)
+        try:
+            y0 = ops.linear(x, w, b, None, EPI_GELU)
+        finally:
+            L.set_option("nt_ragged", 1)
+    # rows of the streaming head: same kernel, same arithmetic -> identical bits; the tail rows come from the 128 x 128 kernel in the
+    # split scheme (16x16x32 MFMA, different summation tree) and only have to agree to rounding
+    assert torch.equal(y1[:33024], y0[:33024])
+    assert (y1[33024:].float() - y0[33024:].float()).abs().max().item() <= 2e-2
 
 
 def _rot_ref(t, A, B):

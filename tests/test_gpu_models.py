@@ -372,6 +372,29 @@ def test_timesformer_golden(dev, golden, dtype, fixture):
             assert (got - ref).abs().max().item() <= tol_g * max(ref.abs().max().item(), floor), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_gather_rows_rot_equals_gather_then_rotary(dev, dtype):
+    """the one-pass regroup + rotary of the divided attention == meant_gather_rows followed by meant_rotary_qk in place, bit for bit
+    (zero rows for index -1, partial rotary dim, v untouched)"""
+    from meant_amd import _lib
+    from meant_amd.ops import _p, _dt, _stream, check, gather_rows
+    lib = _lib.lib
+    rs = np.random.RandomState(3)
+    rows, S, H, Dh, R = 500, 13, 3, 64, 48
+    src = torch.from_numpy(rs.standard_normal((rows, 3 * H * Dh)).astype("float32")).to(dev).to(dtype)
+    n = 40 * S
+    idx = torch.from_numpy(rs.randint(0, rows, size=n).astype("int32")).to(dev)
+    idx[::7] = -1
+    tabs = [torch.from_numpy(rs.standard_normal((S, R)).astype("float32")).to(dev) for _ in range(4)]
+    a = gather_rows(src, idx)
+    check(lib.meant_rotary_qk(_p(a), n, S, H, Dh, R, *[_p(t_) for t_ in tabs], 0, _dt(a), _stream()), "rotary_qk")
+    b = torch.empty_like(a)
+    check(lib.meant_gather_rows_rot(_p(src), _p(idx), _p(b), n, S, H, Dh, R, *[_p(t_) for t_ in tabs], _dt(b), _stream()), "gather_rows_rot")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(b[::7], torch.zeros_like(b[::7]))
+
+
 @pytest.mark.gpu
 def test_dropout_kernel_statistics_and_backward(dev):
     """meant_dropout (the TimeSformer's attention / feed-forward dropouts, src/meant/timesformer_pytorch.py:70,101): keep rate

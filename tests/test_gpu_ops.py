@@ -319,6 +319,53 @@ def test_head_dim_96_runs_on_the_native_kernels(M, O, dev):
         compare_param_grads(ref, hip, torch.bfloat16, kind)
 
 
+@pytest.mark.parametrize("kind,G,S,H,d", [("pixel", 5, 13, 12, 768), ("xpos", 6, 13, 2, 128), ("xpos", 3, 16, 8, 768), ("pixel", 3, 16, 2, 256),
+                                          ("xpos", 4, 7, 1, 128), ("pixel", 9, 2, 3, 192)])
+def test_short_sequences_take_the_one_wave_kernels(M, O, dev, kind, G, S, H, d):
+    """S <= 16 (the time half of the divided space-time attention: 1 + 12 tokens per group) runs on attn_short.hip, one wave
+    per (group, head): values against the oracle (causal + padding incl. a fully padded group, and unmasked), head dims 64 /
+    96 / 128, and against the tiled flash kernels on the same inputs (MEANT_OPT attn_short = 0); the route counters say which ran"""
+    from meant_amd import _lib
+    ref, hip = _attn_pair(M, O, kind, H, d, dev)
+    rs = np.random.RandomState(17 * S + d)
+    x = t(rs.standard_normal((G, S, d)).astype("float32"))
+    dy = t(rs.standard_normal((G, S, d)).astype("float32"))
+    mask = torch.ones(G, S)
+    if kind == "xpos" and S > 1:
+        mask[0, S // 2:] = 0
+        mask[1, 1:S - 1] = 0
+        mask[G - 1, :] = 0
+    xq, dyq = x.bfloat16().float(), dy.bfloat16().float()
+    xr = xq.clone().requires_grad_()
+    yr = ref(xr, mask) if kind == "xpos" else ref(xr)
+    yr.backward(dyq)
+
+    def run():
+        for p_ in hip.parameters():
+            p_.grad = None
+        xh = x.to(dev).bfloat16().requires_grad_()
+        yh = hip(xh, mask.to(dev)) if kind == "xpos" else hip(xh)
+        yh.backward(dy.to(dev).bfloat16())
+        return yh.detach().float().cpu(), xh.grad.float().cpu()
+
+    _lib.route_reset()
+    y1, g1 = run()
+    assert _lib.route_count("attn_short") == 2 and _lib.route_count("attn_fwd") + _lib.route_count("attn_fwd_d96") + _lib.route_count("attn_fwd_d128") == 0
+    tol = TOL[torch.bfloat16]
+    assert_close(y1, yr, tol["out"] * 4, "y")
+    assert_grad_close(g1, xr.grad, tol["gelem"], "dx")
+    compare_param_grads(ref, hip, torch.bfloat16, kind)
+    _lib.set_option("attn_short", 0)
+    try:
+        _lib.route_reset()
+        y0, g0 = run()
+        assert _lib.route_count("attn_short") == 0
+    finally:
+        _lib.set_option("attn_short", 1)
+    assert_close(y1, y0, tol["out"] * 4, "short vs tiled: y")
+    assert_grad_close(g1, g0, tol["gelem"], "short vs tiled: dx")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_temporal_golden(M, O, dev, golden, dtype):
     g = golden("temporal_h12_d1536_l12")
