@@ -77,6 +77,13 @@ template <> struct Vec8<bf16> {
   __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
 };
 
+// one rotary pair (2j, 2j+1) with the products contracted the same way wherever it is evaluated (a free choice of fma by the
+// compiler made the fused regroup + rotary pass differ from the in-place kernel in the last bit)
+__device__ __forceinline__ void rotary_pair(float t0, float t1, float a0, float a1, float b0, float b1, float& o0, float& o1) {
+  o0 = __builtin_fmaf(t0, a0, -(t1 * b0));
+  o1 = __builtin_fmaf(t1, a1, t0 * b1);
+}
+
 template <typename T> __device__ __forceinline__ Vec8<T> load8(const T* p);
 template <> __device__ __forceinline__ Vec8<float> load8<float>(const float* p) {
   Vec8<float> r; r.lo = *reinterpret_cast<const f32x4*>(p); r.hi = *reinterpret_cast<const f32x4*>(p + 4); return r;

@@ -63,9 +63,10 @@ __global__ __launch_bounds__(DIV_THREADS) void gather_rows_rot_kernel(const T* _
         Vec8<T> o;
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-          const float t0 = v.get(k), t1 = v.get(k + 1);
-          o.set(k, t0 * A[k] - t1 * B[k]);
-          o.set(k + 1, t1 * A[k + 1] + t0 * B[k + 1]);
+          float o0, o1;
+          rotary_pair(v.get(k), v.get(k + 1), A[k], A[k + 1], B[k], B[k + 1], o0, o1);
+          o.set(k, o0);
+          o.set(k + 1, o1);
         }
         v = o;
       }

@@ -18,6 +18,7 @@ struct GemmF32Args {
   const void* residual;     // same strides as C, or null
   void* preact;             // same strides as C, or null (value before the activation)
   int epilogue;             // meant_epilogue flags
+  int ksplit = 0;           // 0: never split K; -1: the launcher may split K over several workgroups per tile (float atomics)
 };
 int gemm_f32_launch(const GemmF32Args& a, hipStream_t stream);
 

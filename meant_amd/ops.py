@@ -941,6 +941,7 @@ class _Embedding(torch.autograd.Function):
               "embedding_fwd")
         ctx.save_for_backward(ids_c)
         ctx.meta = (V, d)
+        ctx.table = table                                # the Parameter itself: its gradient sink, if any, is looked up in backward
         return out
 
     @staticmethod
@@ -948,15 +949,23 @@ class _Embedding(torch.autograd.Function):
         (ids_c,) = ctx.saved_tensors
         V, d = ctx.meta
         dout = _c(dout)
-        dtab = torch.zeros((V, d), device=dout.device, dtype=torch.float32)
+        # with a gradient sink (GradReducer(direct_grads=True)) the rows are summed straight into the reducer's bucket view:
+        # no [V, d] zeros + autograd add per step (0.8 GB of traffic at V = 64001)
+        sink = _sink_of(ctx.table) if grad_sinks else None
+        if sink is not None and (sink[1].shape != (V, d) or not sink[1].is_contiguous()):
+            sink = None
+        dtab = sink[1] if sink is not None else torch.zeros((V, d), device=dout.device, dtype=torch.float32)
         n = ids_c.numel()
-        if d <= 1024 and n >= 4096:
+        if d <= 1024 and d % 8 == 0 and n >= 4096:
             # index preparation (a sort of the token ids) is host-side plumbing; the reduction itself is the HIP kernel
             sorted_ids, order = torch.sort(ids_c.view(-1))
             check(lib.meant_embedding_bwd_sorted(_p(dout), _p(sorted_ids), _p(order), _p(dtab), n, d, V, _dt(dout), _stream()),
                   "embedding_bwd_sorted")
         else:
             check(lib.meant_embedding_bwd(_p(dout), _p(ids_c), _p(dtab), n, d, V, _dt(dout), _stream()), "embedding_bwd")
+        if sink is not None:
+            sink[2](ctx.table)
+            return None, None, None
         return None, dtab, None
 
 
