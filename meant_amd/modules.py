@@ -376,16 +376,26 @@ def _run_encoder(enc, x, *args, checkpoint: bool = False, **kw):
     return enc(x, *args, **kw)
 
 
-def _run_stack(encoders, x, *args, checkpoint: bool = False):
+def _ckpt_setting(model):
+    """model.activation_checkpointing: False / True (every encoder layer is recomputed in backward) / an int n (only the first n
+    layers of each stack are: their recomputation comes last in backward, when the later layers' activations are already
+    freed, so the peak is the (layers - n) kept layers -- 12 layers at 128 samples per GPU fit the 288 GB with n = 4 and pay a
+    third of the full recomputation)"""
+    v = getattr(model, "activation_checkpointing", False)
+    return v if isinstance(v, bool) else int(v)
+
+
+def _run_stack(encoders, x, *args, checkpoint=False):
     """all encoder layers of one stack; returns either the token tensor, or -- with POOL_LAST_LINEAR -- the
-    (h, res, weight, bias) part that ops.pool_linear_cat pools"""
+    (h, res, weight, bias) part that ops.pool_linear_cat pools.  checkpoint: bool, or the number of leading layers to recompute"""
     n = len(encoders)
     for i, enc in enumerate(encoders):
+        ck = checkpoint if isinstance(checkpoint, bool) else i < checkpoint
         last = enc.encode2[-1]
         if POOL_LAST_LINEAR and i == n - 1 and isinstance(last, Linear):
-            h, res = _run_encoder(enc, x, *args, checkpoint=checkpoint, pool=True)
+            h, res = _run_encoder(enc, x, *args, checkpoint=ck, pool=True)
             return (h, res, last.weight, last.bias)
-        x = _run_encoder(enc, x, *args, checkpoint=checkpoint)
+        x = _run_encoder(enc, x, *args, checkpoint=ck)
     return x
 
 
@@ -460,7 +470,7 @@ class meant(nn.Module):
         # stack runs on a second HIP stream so that kernels with different bottlenecks (HBM-bound norms, load-path-bound
         # GEMMs, issue-bound attention) of the two stacks can share the chip.  Autograd replays each backward op on the
         # stream of its forward op, so the backward passes overlap the same way.
-        ck = bool(getattr(self, "activation_checkpointing", False))
+        ck = _ckpt_setting(self)
         side = _side_stream(images.device) if (TWO_STREAMS and images.is_cuda and not ck) else None
         if side is not None:
             main = torch.cuda.current_stream()
