@@ -91,6 +91,24 @@ template <> __device__ __forceinline__ Vec8<float> load8<float>(const float* p) 
 template <> __device__ __forceinline__ Vec8<bf16> load8<bf16>(const bf16* p) {
   Vec8<bf16> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r;
 }
+// streaming forms for tensors a kernel touches once (nontemporal: no reuse expected in L2)
+template <typename T> __device__ __forceinline__ Vec8<T> load8s(const T* p);
+template <> __device__ __forceinline__ Vec8<float> load8s<float>(const float* p) {
+  Vec8<float> r;
+  r.lo = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  r.hi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+  return r;
+}
+template <> __device__ __forceinline__ Vec8<bf16> load8s<bf16>(const bf16* p) {
+  Vec8<bf16> r; r.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); return r;
+}
+template <typename T> __device__ __forceinline__ void store8s(T* p, const Vec8<T>& v);
+template <> __device__ __forceinline__ void store8s<float>(float* p, const Vec8<float>& v) {
+  __builtin_nontemporal_store(v.lo, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(v.hi, reinterpret_cast<f32x4*>(p + 4));
+}
+template <> __device__ __forceinline__ void store8s<bf16>(bf16* p, const Vec8<bf16>& v) {
+  __builtin_nontemporal_store(v.v, reinterpret_cast<bf16x8*>(p));
+}
 template <typename T> __device__ __forceinline__ void store8(T* p, const Vec8<T>& v);
 template <> __device__ __forceinline__ void store8<float>(float* p, const Vec8<float>& v) {
   *reinterpret_cast<f32x4*>(p) = v.lo; *reinterpret_cast<f32x4*>(p + 4) = v.hi;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(DIV_THREADS) void gather_rows_kernel(const T* __res
 #pragma unroll
         for (int k = 0; k < 8; ++k) v.set(k, 0.f);
       }
-      store8<T>(dst + r * W + ch * 8, v);
+      store8s<T>(dst + r * W + ch * 8, v);
     }
   }
 }
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(DIV_THREADS) void gather_rows_rot_kernel(const T* _
         }
         v = o;
       }
-      store8<T>(dst + r * W + ch * 8, v);
+      store8s<T>(dst + r * W + ch * 8, v);
     }
   }
 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(DIV_THREADS) void group_scatter_rows_kernel(const T
     const int gs = (int)(r - b * (int64_t)G * S);
     if (gs % S == 0) continue;                        // position 0 of a group is the shared cls row
     T* d = dsrc + (b * L + index[gs]) * W;
-    for (int ch = lane; ch < nch; ch += 64) store8<T>(d + ch * 8, load8<T>(ddst + r * W + ch * 8));
+    for (int ch = lane; ch < nch; ch += 64) store8s<T>(d + ch * 8, load8s<T>(ddst + r * W + ch * 8));
   }
 }
 // the cls row: dsrc[b, index[0], :] = sum_g ddst[b, g, 0, :]   (fp32 sum, fixed order)

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(EW_THREADS) void patchify_c4_kernel(const TI* __res
       o.set(c, to_f(src[0]));
       o.set(4 + c, to_f(src[1]));
     }
-    store8<T>(out + r * P + (p1 * p + 2 * pp) * 4, o);
+    store8s<T>(out + r * P + (p1 * p + 2 * pp) * 4, o);
   }
 }
 
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(EW_THREADS) void geglu_fwd_kernel(const T* __restri
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cw;
     const int c = (int)(i - r * cw) * 8;
-    const Vec8<T> a = load8<T>(h + r * 2 * w + c), g = load8<T>(h + r * 2 * w + w + c);
+    const Vec8<T> a = load8s<T>(h + r * 2 * w + c), g = load8s<T>(h + r * 2 * w + w + c);
     Vec8<T> o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o.set(k, a.get(k) * gelu_erf(g.get(k)));
-    store8<T>(y + r * w + c, o);
+    store8s<T>(y + r * w + c, o);
   }
 }
 template <typename T>
@@ -232,15 +232,15 @@ __global__ __launch_bounds__(EW_THREADS) void geglu_bwd_kernel(const T* __restri
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cw;
     const int c = (int)(i - r * cw) * 8;
-    const Vec8<T> a = load8<T>(h + r * 2 * w + c), g = load8<T>(h + r * 2 * w + w + c), d = load8<T>(dy + r * w + c);
+    const Vec8<T> a = load8s<T>(h + r * 2 * w + c), g = load8s<T>(h + r * 2 * w + w + c), d = load8s<T>(dy + r * w + c);
     Vec8<T> da, dg;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       da.set(k, d.get(k) * gelu_erf(g.get(k)));
       dg.set(k, d.get(k) * a.get(k) * gelu_erf_grad(g.get(k)));
     }
-    store8<T>(dh + r * 2 * w + c, da);
-    store8<T>(dh + r * 2 * w + w + c, dg);
+    store8s<T>(dh + r * 2 * w + c, da);
+    store8s<T>(dh + r * 2 * w + w + c, dg);
   }
 }
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restr
       Vec8<T> o;
 #pragma unroll
       for (int k = 0; k < 8; ++k) o.set(k, v.get(k));
-      store8<T>(out + r * d + ch * 8, o);
+      store8s<T>(out + r * d + ch * 8, o);
     }
   }
 }
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const T* __re
         ids4[u] = __shfl(my_id, t, 64);
         const long long ord = __shfl(my_ord, t, 64);
         const T* src = dout + ord * d;
-        if (has0) r0[u] = load8<T>(src + lane * 8);
-        if (has1) r1[u] = load8<T>(src + (lane + 64) * 8);
+        if (has0) r0[u] = load8s<T>(src + lane * 8);
+        if (has1) r1[u] = load8s<T>(src + (lane + 64) * 8);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -103,6 +103,7 @@ __device__ __forceinline__ void rot_apply8(float (&v)[8], const f32x4& a0, const
   }
 }
 
+template <bool STREAM_OUT = false>
 __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, int64_t n, float (&v)[8], bool vec_ok) {
   if (vec_ok) {
     if (a.preact) {
@@ -138,7 +139,8 @@ __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, 
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-    *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
+    if (STREAM_OUT) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n));
+    else *reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n) = o;
   } else {
     for (int e = 0; e < 8 && n + e < a.N; ++e) {
       float x = v[e];
@@ -511,7 +513,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int r = j * 16 + frow;
+          // DIRECT: MFMA block j is fed the W rows 32 (j / 2) + 8 (frow / 4) + 4 (j % 2) + frow % 4, so that a lane's results of
+          // blocks 2 jp and 2 jp + 1 are EIGHT CONSECUTIVE output columns (32 jp + 8 fkg ..) and can be stored without a transpose
+          const int r = (DBG & 32) ? 32 * (j >> 1) + 8 * (frow >> 2) + 4 * (j & 1) + (frow & 3) : j * 16 + frow;
           bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
         }
         __builtin_amdgcn_s_setprio(1);
@@ -565,7 +569,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
     // only talks to its own 4 KiB patch in each of them, so there is no workgroup barrier in here.  Lane layout in:
     // acc[i][j] = C[i*16 + frow][j*16 + 4*fkg .. +3]; out: lane l owns 8 consecutive columns (l & 7) * 8 of row
     // (l >> 3) + 8h, i.e. one store instruction writes 8 complete 128-byte lines.
-    if (!(DBG & 4)) {
+    if ((DBG & 32) && !ROT) {
+      // lab: direct epilogue -- no LDS transpose; a store instruction writes 16 rows x 64 contiguous bytes
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int64_t n = n0 + wn * 64 + 32 * jp + 8 * fkg;
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias[e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias[4 + e]; }
+          nt_store_row8(a, m0 + wm * 128 + i * 16 + frow, n, v, true);
+        }
+      }
+    } else if (!(DBG & 4)) {
       const int f3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, f4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
       float* patch[2] = {reinterpret_cast<float*>(smem + f3 * T2_BYTES + wave * 4096),
                          reinterpret_cast<float*>(smem + f4 * T2_BYTES + wave * 4096)};
@@ -629,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[h][e] : hi[h][e - 4]) + bias[e];
             if (DBG & 16) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])); }   // lab: everything but the global store
-            else nt_store_row8(a, m0 + wm * 128 + i * 16 + r, n, v, true);
+            else nt_store_row8<(DBG & 64) != 0>(a, m0 + wm * 128 + i * 16 + r, n, v, true);
           }
         } else {
           // finish both rows, THEN ask for the next round's tables (into the same registers), THEN store

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const 
     Vec8<T> v[C];
     float ss[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = load8<T>(xr + (lane + 64 * c) * 8);
+    for (int c = 0; c < C; ++c) v[c] = load8s<T>(xr + (lane + 64 * c) * 8);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       ss[c] = 0.f;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const 
       Vec8<T> o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o.set(i, (i < 4 ? g0[c][i] : g1[c][i - 4]) * (v[c].get(i) * rr[c]) * km[i]);
-      store8<T>(yr + (lane + 64 * c) * 8, o);
+      store8s<T>(yr + (lane + 64 * c) * 8, o);
     }
   }
 }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
       Vec8<T> v[C];
       float ss[C];
 #pragma unroll
-      for (int c = 0; c < C; ++c) v[c] = load8<T>(xr + (lane + 64 * c) * 8);
+      for (int c = 0; c < C; ++c) v[c] = load8s<T>(xr + (lane + 64 * c) * 8);
       if (GELU_IN) {
 #pragma unroll
         for (int c = 0; c < C; ++c)
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 #pragma unroll
           for (int i = 0; i < 8; ++i) psum[c][i] += o.get(i);
         } else {
-          store8<T>(y + row0 * d + (lane + 64 * c) * 8, o);
+          store8s<T>(y + row0 * d + (lane + 64 * c) * 8, o);
 #pragma unroll
           for (int i = 0; i < 8; ++i) psum[c][i] += v[c].get(i);
         }
@@ -359,15 +359,15 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t o = off + (lane + 64 * c) * 8;
-      if (gelu_pre) pv[c] = load8<T>(gelu_pre + o);
+      if (gelu_pre) pv[c] = load8s<T>(gelu_pre + o);
       if (BC & 4) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_erf_fast(pv[c].get(i)));
-      } else xv[c] = load8<T>(x + o);
+      } else xv[c] = load8s<T>(x + o);
       if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
-      else dv[c] = load8<T>(dy + o);
+      else dv[c] = load8s<T>(dy + o);
       if (BC & 2) rvg[c] = load8<float>(reinterpret_cast<const float*>(dres) + pg * d + col[c]);
-      else if (dres) rv[c] = load8<T>(dres + o);
+      else if (dres) rv[c] = load8s<T>(dres + o);
     }
     float rr[C], cd[C], gd[C][8];
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
         if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
         o.set(i, val);
       }
-      store8<T>(dx + off + (lane + 64 * c) * 8, o);
+      store8s<T>(dx + off + (lane + 64 * c) * 8, o);
     }
   }
   __syncthreads();

@@ -29,7 +29,7 @@ template <int DBG> static void run(const char* name, GemmBf16Args a, int reps) {
          2.0 * a.M * a.N * a.K / ms / 1e9, ms * 1e3 / ksteps);
 }
 int main() {
-  const int64_t shapes[2][3] = {{786432, 768, 768}, {786432, 768, 3072}};
+  const int64_t shapes[3][3] = {{786432, 768, 768}, {786432, 2304, 768}, {786432, 768, 3072}};
   for (auto& sh : shapes) {
     const int64_t M = sh[0], N = sh[1], K = sh[2];
     bf16 *A, *B, *C;
@@ -38,6 +38,10 @@ int main() {
     GemmBf16Args a{};
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
     run<0>("full", a, 10);
+    run<64>("nontemporal C stores", a, 10);
+    run<0>("full", a, 10);
+    run<64>("nontemporal C stores", a, 10);
+    run<32>("direct epilogue (no LDS)", a, 10);
     run<1>("no DMA in loop", a, 10);
     run<16>("epilogue without global stores", a, 10);
     run<8>("waves 4-7 never wait for stores", a, 10);
