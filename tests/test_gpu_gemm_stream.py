@@ -27,7 +27,9 @@ def dev():
 @pytest.fixture()
 def L():
     from meant_amd import _lib
-    saved = {k: _lib.get_option(k) for k in ("nt_dynamic", "nt_grid_cap", "nt_stream", "deterministic")}
+    saved = {k: _lib.get_option(k) for k in ("nt_dynamic", "nt_grid_cap", "nt_stream", "deterministic", "nt_ragged")}
+    for k, v in (("nt_dynamic", 1), ("nt_grid_cap", 0), ("nt_stream", 1), ("deterministic", 0), ("nt_ragged", 1)):
+        _lib.set_option(k, v)                        # the route assertions below are about the default dispatch, whatever the environment says
     _lib.route_reset()
     yield _lib
     for k, v in saved.items():

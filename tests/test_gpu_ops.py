@@ -348,6 +348,8 @@ def test_short_sequences_take_the_one_wave_kernels(M, O, dev, kind, G, S, H, d):
         yh.backward(dy.to(dev).bfloat16())
         return yh.detach().float().cpu(), xh.grad.float().cpu()
 
+    prev = _lib.get_option("attn_short")
+    _lib.set_option("attn_short", 1)
     _lib.route_reset()
     y1, g1 = run()
     assert _lib.route_count("attn_short") == 2 and _lib.route_count("attn_fwd") + _lib.route_count("attn_fwd_d96") + _lib.route_count("attn_fwd_d128") == 0
@@ -361,7 +363,7 @@ def test_short_sequences_take_the_one_wave_kernels(M, O, dev, kind, G, S, H, d):
         y0, g0 = run()
         assert _lib.route_count("attn_short") == 0
     finally:
-        _lib.set_option("attn_short", 1)
+        _lib.set_option("attn_short", prev)
     assert_close(y1, y0, tol["out"] * 4, "short vs tiled: y")
     assert_grad_close(g1, g0, tol["gelem"], "short vs tiled: dx")
 
