@@ -563,6 +563,14 @@ inline int packed_blocks(int64_t groups) {
   int64_t b = ceil_div(groups, 4);
   return (int)(b < 1 ? 1 : (b > NORM_PACKED_BLOCKS ? NORM_PACKED_BLOCKS : b));
 }
+// the packed backward kernels hold two workgroups per CU (205 VGPRs): more than 512 workgroups run in rounds, each paying the
+// prologue (gain loads) and the epilogue (LDS reduction of the gain gradient, partial row) again -- at the MLM step's 32 k rows
+// the 2048-block launch spent two thirds of its 98 us there
+inline int packed_blocks_bwd(int64_t groups) {
+  int64_t b = ceil_div(groups, 4);
+  const int64_t cap = 2 * (int64_t)meant_num_cus();
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
 inline int norm_blocks(int64_t rows) {
   int64_t b = ceil_div(rows, 4);
   return (int)(b < 1 ? 1 : (b > NORM_MAX_BLOCKS ? NORM_MAX_BLOCKS : b));
@@ -612,7 +620,7 @@ extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* sca
   int R, C;
   norm_packing(rows, d, R, C);
   if (R) {
-    const int nbp = packed_blocks(rows / R);
+    const int nbp = packed_blocks_bwd(rows / R);
 #define LAUNCH_BWD(CC)                                                                                                        \
     DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, 0>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
                                                 (const T*)dy, (const T*)x, scale, rinv, (T*)dx, (float*)workspace, rows, (int)d, R, eps,    \
@@ -676,7 +684,7 @@ extern "C" int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const voi
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_pooled: workspace too small");
   int R, C;
   norm_packing(rows, d, R, C);
-  const int nbp = packed_blocks(rows / R);
+  const int nbp = packed_blocks_bwd(rows / R);
   const int bc = (dy_pooled ? 1 : 0) | (dres_pooled ? 2 : 0) | (x ? 0 : 4);
   MEANT_REQUIRE(bc == 1 || bc == 2 || bc == 3 || bc == 5, MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_pooled: unsupported combination");
 #define LAUNCH_BWDP(CC, BB)                                                                                                   \

@@ -27,3 +27,11 @@ for name, p, dr, gp, nb in [("bwd", 0.0, None, None, 3), ("bwd +dres", 0.0, dres
     t = timeit(lambda: check(lib.meant_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), r.data_ptr(), dx.data_ptr(), ds.data_ptr(), rows, d, 1e-8, p, 1234,
                                                    dr.data_ptr() if dr is not None else None, gp.data_ptr() if gp is not None else None, 1, ws.data_ptr(), wsb, st)))
     print(f"{name:28s} {t:.3f} ms  {nb*GB/t:6.2f} TB/s", flush=True)
+# the MLM step's size (64 x 512 tokens): fixed costs of a launch show here
+rows2 = 32768
+for name, dr in [("bwd 32k rows", None), ("bwd +dres 32k rows", dres)]:
+    t = timeit(lambda: check(lib.meant_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), r.data_ptr(), dx.data_ptr(), ds.data_ptr(), rows2, d, 1e-8, 0.0, 1234,
+                                                   dr.data_ptr() if dr is not None else None, None, 1, ws.data_ptr(), wsb, st)), n=50)
+    print(f"{name:28s} {t*1e3:.1f} us", flush=True)
+t = timeit(lambda: check(lib.meant_rmsnorm_fwd(x.data_ptr(), g.data_ptr(), y.data_ptr(), r.data_ptr(), rows2, d, 1e-8, 0.0, 1234, 1, st)), n=50)
+print(f"{'fwd 32k rows':28s} {t*1e3:.1f} us", flush=True)
