@@ -66,14 +66,17 @@ int meant_num_cus(void);
  *   "nt_stream"        1|0   streaming 256x256 NT GEMM / one tile per workgroup           (A/B measurements)
  *   "nt_dynamic"       1|0|3 streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements) /
  *                            only XCD 0 uses its own counter, all other tiles go through the steal path (tests)
- *   "nt_qkv_split"     1|0   fused q|k|v projection as three L2-resident column passes / one pass
  *   "nt_grid_cap"      0|n   cap the streaming GEMM's grid at n workgroups (tests: many tiles per workgroup, steals)
+ *   "nt_ragged"        1|0   M not a multiple of 256: the streaming GEMM's last row tile is moved up to end at row M (it
+ *                            recomputes rows of its neighbour bit-identically) / streaming head + 128 x 128 tail launch
+ *                            (also what operands that alias the output fall back to)
+ *   "attn_short"       1|0   sequences of <= 16 tokens run on the one-wave-per-(group, head) kernels / on the tiled ones
  */
 int meant_set_option(const char* name, int value);
 int meant_get_option(const char* name, int* value);
 /* how many launches took a given kernel route since the last reset ("nt128", "nt256", "nt256s", "nt256s_rot",
- * "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32", "attn_fwd", "attn_fwd_d128",
- * "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96", "attn_generic", "attn_cls");
+ * "nt_split", "nt_overlap", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32", "attn_fwd", "attn_fwd_d128",
+ * "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96", "attn_generic", "attn_cls", "attn_short");
  * -1 for an unknown name.  Tests use it to prove that a shape reaches the kernel it is meant to exercise. */
 int64_t meant_route_count(const char* route);
 void meant_route_reset(void);

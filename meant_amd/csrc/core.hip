@@ -76,7 +76,6 @@ const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"nt_stream", "MEANT_NT_STREAM", 1},           // 0: one-tile-per-workgroup 256x256 NT kernel instead of the streaming one
     {"nt_dynamic", "MEANT_NT_DYNAMIC", 1},         // 0: fixed persistent tile walk; 1: per-XCD counters; 2: draw but ignore (lab); 3: steal-only (tests)
     {"deterministic", "MEANT_DETERMINISTIC", 0},   // 1: parameter gradients are bit-reproducible (ordered reductions, no float atomics)
-    {"nt_qkv_split", "MEANT_NT_QKV_SPLIT", 1},
     {"nt_grid_cap", "MEANT_NT_GRID_CAP", 0},       // tests: cap the streaming GEMM's grid (0 = one workgroup per CU)
     {"attn_short", "MEANT_ATTN_SHORT", 1},         // 0: sequences of <= 16 tokens take the tiled flash kernels instead of attn_short.hip
     {"nt_ragged", "MEANT_NT_RAGGED", 1},           // 0: ragged M as streaming head + 128 x 128 tail launch instead of the overlapped last row tile

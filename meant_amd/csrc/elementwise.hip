@@ -417,18 +417,29 @@ constexpr int EMB_SEG = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const T* __restrict__ dout, const int64_t* __restrict__ sorted_ids,
                                                                     const int64_t* __restrict__ order, float* __restrict__ dtable,
-                                                                    int64_t n, int d, int64_t V) {
+                                                                    int64_t n, int d, int64_t V, int det) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * EMB_SEG;
+  int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * EMB_SEG;
   if (j0 >= n) return;
-  const int64_t j1 = j0 + EMB_SEG < n ? j0 + EMB_SEG : n;
+  int64_t j1 = j0 + EMB_SEG < n ? j0 + EMB_SEG : n;
+  if (det) {
+    // option "deterministic": no atomics.  A run belongs to the wave in whose stretch it STARTS: that wave follows it to its end
+    // (however far), the others skip the part of their stretch that continues an earlier run.  Slow for a hot id; a debugging mode.
+    if (j0 > 0) {
+      const int64_t prev = sorted_ids[j0 - 1];
+      while (j0 < j1 && sorted_ids[j0] == prev) ++j0;
+      if (j0 == j1) return;
+    }
+    const int64_t last = sorted_ids[j1 - 1];
+    while (j1 < n && sorted_ids[j1] == last) ++j1;
+  }
   const int nch = d >> 3;                              // d % 8 == 0, d <= 1024
   const bool has1 = lane + 64 < nch, has0 = lane < nch;
   float acc0[8], acc1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc0[e] = acc1[e] = 0.f;
   int64_t cur = sorted_ids[j0];
-  bool shared = j0 > 0 && sorted_ids[j0 - 1] == cur;   // the first run started in the previous stretch
+  bool shared = !det && j0 > 0 && sorted_ids[j0 - 1] == cur;   // the first run started in the previous stretch
 
   auto flush = [&](int64_t id, bool atomic) {
     if (id < 0 || id >= V) return;
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const T* __re
       }
     }
   }
-  flush(cur, shared || (j1 < n && sorted_ids[j1] == cur));   // ... or continues into the next stretch
+  flush(cur, !det && (shared || (j1 < n && sorted_ids[j1] == cur)));   // ... or continues into the next stretch
 }
 
 }  // namespace
@@ -708,7 +719,7 @@ extern "C" int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorte
   const int64_t nb = ceil_div(n, 4 * EMB_SEG);
   DISPATCH_DTYPE(dtype, T,
                  hipLaunchKernelGGL(embedding_bwd_sorted_kernel<T>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const T*)dout,
-                                    sorted_ids, order, dtable, n, (int)d, V));
+                                    sorted_ids, order, dtable, n, (int)d, V, meant_opt(MEANT_OPT_DETERMINISTIC) != 0));
   MEANT_LAUNCH_CHECK("embedding_bwd_sorted");
   return MEANT_OK;
 }

@@ -429,6 +429,11 @@ def _bwd_dw(dy2, x2, dw, db):
 grad_sinks = {}
 
 
+def _lib_option(name: str) -> int:
+    from . import _lib
+    return _lib.get_option(name)
+
+
 def _sink_of(param):
     ent = grad_sinks.get(id(param))
     if ent is None or ent[0]() is not param:
@@ -956,7 +961,7 @@ class _Embedding(torch.autograd.Function):
             sink = None
         dtab = sink[1] if sink is not None else torch.zeros((V, d), device=dout.device, dtype=torch.float32)
         n = ids_c.numel()
-        if d <= 1024 and d % 8 == 0 and n >= 4096:
+        if d <= 1024 and d % 8 == 0 and (n >= 4096 or _lib_option("deterministic")):   # the other kernel is float atomics per token
             # index preparation (a sort of the token ids) is host-side plumbing; the reduction itself is the HIP kernel
             sorted_ids, order = torch.sort(ids_c.view(-1))
             check(lib.meant_embedding_bwd_sorted(_p(dout), _p(sorted_ids), _p(order), _p(dtab), n, d, V, _dt(dout), _stream()),

@@ -472,6 +472,20 @@ def test_embedding_backward_sorted_path(M, dev, dtype, V, d, B, S):
     torch.nn.functional.embedding(ids, tr).backward(ge.to(dtype).float())
     assert_grad_close(th.grad, tr.grad, 1e-5 if dtype == torch.float32 else 2e-3, "d embedding (sorted)")
     assert th.grad[8:].abs().sum() > 0 and torch.equal(th.grad.cpu() == 0, tr.grad == 0)
+    # option "deterministic": runs are summed by the wave in whose stretch they start, no atomics -> bit-identical repeats
+    from meant_amd import _lib
+    prev = _lib.get_option("deterministic")
+    _lib.set_option("deterministic", 1)
+    try:
+        grads = []
+        for _ in range(2):
+            t2 = table.to(dev).requires_grad_()
+            ops.embedding(ids.to(dev), t2, dtype).backward(ge.to(dev).to(dtype))
+            grads.append(t2.grad.clone())
+    finally:
+        _lib.set_option("deterministic", prev)
+    assert torch.equal(grads[0], grads[1])
+    assert_grad_close(grads[0], tr.grad, 1e-5 if dtype == torch.float32 else 2e-3, "d embedding (sorted, deterministic)")
 
 
 def test_errors_are_loud(M, dev):
