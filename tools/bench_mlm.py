@@ -36,11 +36,15 @@ def main():
     labels[pick] = torch.from_numpy(rs.randint(2, V, int(pick.sum())))
     labels = labels.to(dev)
 
+    # gradients go where meant_amd.train.TrainStep puts them: flat fp32 buckets, written by the backward kernels directly
+    from meant_amd.parallel import GradReducer
+    red = GradReducer(model.parameters(), direct_grads=True)
+
     def step():
-        for p in model.parameters():
-            p.grad = None
+        red.prepare()
         loss = model.loss(ids, mask, labels)
         loss.backward()
+        red.wait()
         return loss
 
     for _ in range(2):
