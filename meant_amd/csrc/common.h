@@ -151,6 +151,17 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float phi = x < 0.f ? half_erfc : 1.0f - half_erfc;
   return x * phi;
 }
+// Phi(x) alone (same rational erfc): gelu(x) = x * Phi(x), gelu'(x) = Phi(x) + x * pdf(x)
+__device__ __forceinline__ float gelu_phi_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return x < 0.f ? half_erfc : 1.0f - half_erfc;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);

@@ -360,9 +360,9 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
     for (int c = 0; c < C; ++c) {
       const int64_t o = off + (lane + 64 * c) * 8;
       if (gelu_pre) pv[c] = load8s<T>(gelu_pre + o);
-      if (BC & 4) {
+      if (BC & 4) {                                   // x = pre * Phi(pre) is not stored: keep Phi (x and gelu' are both one multiply-add away)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_erf_fast(pv[c].get(i)));
+        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
       } else xv[c] = load8s<T>(x + o);
       if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
       else dv[c] = load8s<T>(dy + o);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float dyi = ((BC & 1) ? dvg[c].get(i) * inv_group : dv[c].get(i)) * km[i];
-        const float xi = xv[c].get(i);
+        const float xi = (BC & 4) ? pv[c].get(i) * xv[c].get(i) : xv[c].get(i);
         gacc[c][i] += dyi * xi * rr[c];
         const float t = (i < 4 ? g0[c][i] : g1[c][i - 4]) * dyi;
         gd[c][i] = t;
@@ -407,10 +407,14 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
       Vec8<T> o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float val = rr[c] * gd[c][i] - kk[c] * xv[c].get(i);
+        const float xi2 = (BC & 4) ? pv[c].get(i) * xv[c].get(i) : xv[c].get(i);
+        float val = rr[c] * gd[c][i] - kk[c] * xi2;
         if (BC & 2) val += rvg[c].get(i) * inv_group;
         else if (dres) val += rv[c].get(i);
-        if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
+        if (BC & 4) {                                   // gelu'(pre) = Phi + pre * pdf(pre), Phi kept from the first pass
+          const float pr = pv[c].get(i);
+          val *= fmaf(pr * 0.39894228040143268f, __builtin_amdgcn_exp2f(-0.72134752044448170f * pr * pr), xv[c].get(i));
+        } else if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
         o.set(i, val);
       }
       store8s<T>(dx + off + (lane + 64 * c) * 8, o);
