@@ -194,9 +194,22 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
 // 64-bit hash decides 4 elements, 16 bits each (keep iff the 16-bit draw >= p * 65536), so the price per element is a
 // quarter of a splitmix round.  The multiplier is 1 / (1 - p_q) for the quantised p_q the draws really implement.
 // Forward and backward call this with the same (seed, base) and get the same mask.
+// When p is a multiple of 1/256 (nn.Dropout()'s default 0.5 is) 8 bits per element decide exactly the same keep probability,
+// and ONE hash serves all 8 elements: the 64-bit multiplies of a splitmix round are quarter-rate integer multiplies, a round per
+// four elements was a quarter of the VALU time of the gelu-on-load norm kernels.
 __device__ __forceinline__ void keep_scale8(float p, uint64_t seed, uint64_t base, float (&m)[8]) {
   const unsigned thr = (unsigned)(p * 65536.0f);
   const float sc = 65536.0f / (float)(65536u - thr);
+  if ((thr & 0xffu) == 0) {                            // wave-uniform: p comes from the kernel arguments
+    uint64_t z = seed + ((base >> 3) | (1ull << 62)) * 0x9E3779B97F4A7C15ull;     // a counter space of its own
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const unsigned thr8 = thr >> 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = ((unsigned)(z >> (8 * q)) & 0xffu) >= thr8 ? sc : 0.0f;
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     uint64_t z = seed + ((base >> 2) + h) * 0x9E3779B97F4A7C15ull;

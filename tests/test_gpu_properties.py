@@ -104,6 +104,9 @@ def test_deterministic_forward_and_dropout_seeding(dev):
         m.train()
         torch.manual_seed(3); t1 = m(ids, img, mask)
         torch.manual_seed(3); t2 = m(ids, img, mask)
-        torch.manual_seed(4); t3 = m(ids, img, mask)
+        others = []
+        for sd in (4, 5, 6, 7):                              # the output is two bf16-rounded numbers: one other seed may round to the same pair
+            torch.manual_seed(sd)
+            others.append(m(ids, img, mask))
         m.eval()
-    assert torch.equal(t1, t2) and not torch.equal(t1, t3) and not torch.equal(t1, a)
+    assert torch.equal(t1, t2) and any(not torch.equal(t1, t3) for t3 in others) and not torch.equal(t1, a)
