@@ -147,6 +147,24 @@ def test_ragged_rows_are_bit_identical_between_the_two_schemes(L, dev):
     assert (y1[33024:].float() - y0[33024:].float()).abs().max().item() <= 2e-2
 
 
+def test_ragged_rows_with_an_in_place_residual_fall_back_to_the_split(L, dev):
+    """y = x W^T + y through the C ABI with residual == y (in place): the overlapped last tile would read rows its neighbour
+    has already overwritten, so the launcher must take the head + tail split -- and the result must be right"""
+    M_, N, K = 33024 + 60, 768, 768
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.standard_normal((M_, K)).astype("float32")).to(dev).to(BF)
+    w = torch.from_numpy((rs.standard_normal((N, K)) * 0.05).astype("float32")).to(dev).to(BF)
+    y0 = torch.from_numpy(rs.standard_normal((M_, N)).astype("float32")).to(dev).to(BF)
+    y = y0.clone()
+    L.route_reset()
+    L.check(L.lib.meant_linear_fwd(x.data_ptr(), K, w.data_ptr(), None, y.data_ptr(), N, y.data_ptr(), N, None, M_, N, K, L.EPI_RESIDUAL, 1,
+                                   torch.cuda.current_stream().cuda_stream), "linear_fwd")
+    torch.cuda.synchronize()
+    assert L.route_count("nt_split") == 1 and L.route_count("nt_overlap") == 0
+    ref = x.float() @ w.float().t() + y0.float()
+    assert_close(y, ref, 3e-2 * max(1.0, ref.abs().max().item()), "in-place residual")
+
+
 def _rot_ref(t, A, B):
     """out[c] = t[c] A[pos, c] + rot(t)[c] B[pos, c], rot(t)[2j] = -t[2j+1], rot(t)[2j+1] = t[2j]   (include/meant_hip.h)"""
     r = torch.empty_like(t)
