@@ -7,6 +7,10 @@ statistics/softmax/accumulators), synthetic inputs, random-init weights -- BASEL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W                            # N ranks, RCCL grad all-reduce
 
+`--model meant_vqa` (BASELINE.json configs[4]: image + text, no lag axis, 3129 classes) and `--model meant_vision`
+(configs[1]: images only, lag 1) run the same step with the same JSON contract on those classes; the default is the
+headline `meant`.
+
 A step = one pass of the hot path over one batch: forward (train mode: the languageEncoder's Dropout(0.5)
 is live, fused into the RMSNorm kernel), cross-entropy on the probabilities (in_loop_train.py:232),
 backward to every parameter gradient (incl. the 64001x768 embedding), and for N>1 the bucketed
@@ -44,10 +48,29 @@ PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md (~8 TB/s; ~6.3 TB/s i
 V, D, H, L, S, IMG, P, C, NCLS = 64001, 768, 12, 12, 512, 224, 16, 4, 2
 
 
+MODEL = "meant"                # --model: meant (configs[2]/[3], the headline) | meant_vqa (configs[4]) | meant_vision (configs[1])
+
+
+def _shape():
+    """(lag, text tokens per lag step, patches per lag step, classes, width of the fused feature) of the benchmarked model"""
+    n = (IMG // P) ** 2
+    if MODEL == "meant":
+        return L, S, n, NCLS, 2 * D
+    if MODEL == "meant_vqa":
+        return 1, S, n, 3129, 2 * D
+    return 1, 0, n, NCLS, D        # meant_vision
+
+
 def flops_per_sample(E: int) -> float:
-    """fwd = 3.88 + 91.26 E GFLOP (full-square attention), fwd+bwd = 3x: the work of the
-    reference's own graph."""
-    return 3.0 * (3.88 + 91.26 * E) * 1e9
+    """SURVEY.md 8(d), the work of the reference's own graph, fwd+bwd = 3 x fwd, full-square attention.  Per lag step:
+    patch-embed 2 n P d; a vision layer 16 d^2 n + 4 n^2 d; a language layer 16 d^2 S + 4 S^2 d; then the temporal encoder
+    (`meant`: 2 D_t^2 (3 lag + 3); the single-modality / vqa classes: their own small heads).  `meant` at lag 12:
+    fwd = 3.88 + 91.26 E GFLOP."""
+    lag, s, n, ncls, dt = _shape()
+    fwd = lag * (2.0 * n * (C * P * P) * D + E * (16.0 * D * D * n + 4.0 * n * n * D) + (E * (16.0 * D * D * s + 4.0 * s * s * D) if s else 0.0))
+    fwd += 2.0 * dt * dt * (3 * lag + 3) if MODEL != "meant_vqa" else 0.0
+    fwd += 2.0 * dt * ncls
+    return 3.0 * fwd
 
 
 def flops_per_sample_executed(E: int) -> float:
@@ -55,12 +78,13 @@ def flops_per_sample_executed(E: int) -> float:
     (meant_amd.modules.COMPOSE_PRE_LINEAR), which removes 2 d^2 FLOPs per token per layer in forward and twice
     that in backward, and the stacks' final Linear commutes with the mean-pool; everything else as above."""
     import meant_amd.modules as mm
-    per_linear = 3.0 * 2.0 * D * D * L * (S + (IMG // P) ** 2)          # one Linear(d, d) on every token: fwd + dX + dW
+    lag, s, n, _, _ = _shape()
+    per_linear = 3.0 * 2.0 * D * D * lag * (s + n)                       # one Linear(d, d) on every token: fwd + dX + dW
     saved = E * per_linear if mm.COMPOSE_PRE_LINEAR else 0.0
     # the last Linear of the last layer of each stack is evaluated on the pooled features (meant_amd.modules.POOL_LAST_LINEAR:
     # mean_s(h W^T + b + x) = mean_s(h) W^T + b + mean_s(x)); what replaces it is S (resp. 196) times smaller
     if mm.POOL_LAST_LINEAR:
-        saved += per_linear - 3.0 * 2.0 * D * D * L * 2
+        saved += per_linear - 3.0 * 2.0 * D * D * lag * (2 if s else 1)
     return flops_per_sample(E) - saved
 
 
@@ -198,58 +222,80 @@ class GemmTimer:
 def build_model(E: int, device):
     import meant_amd
     torch.manual_seed(1234)
-    emb = torch.nn.Embedding(V, D)
-    m = meant_amd.meant(D, D, 4, IMG, IMG, P, L, NCLS, emb, num_heads=H, num_encoders=E, channels=C)
+    if MODEL == "meant":
+        m = meant_amd.meant(D, D, 4, IMG, IMG, P, L, NCLS, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C)
+    elif MODEL == "meant_vqa":          # meant_vqa(768, 768, 4, 224, 224, 16, lag=1, num_classes=3129, ...)
+        m = meant_amd.meant_vqa(D, D, 4, IMG, IMG, P, 1, 3129, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C)
+    else:                               # meant_vision(768, 4, 224, 224, 16, lag=1, num_classes=2, ...)
+        m = meant_amd.meant_vision(D, 4, IMG, IMG, P, 1, NCLS, num_heads=H, num_encoders=E, channels=C)
     m.compute_dtype = torch.bfloat16
     return m.to(device)
 
 
 def make_batch(B: int, rank: int, device):
+    """(model inputs, target): synthetic, seeded per rank (rank r holds rows [B r, B r + B) of the global batch)"""
+    lag, s, n, ncls, _ = _shape()
     rs = np.random.RandomState(99 + rank)
-    tweets = torch.from_numpy(rs.randint(0, V, (B, L, S)).astype("int64")).to(device)
-    images = torch.randn(B, L, C, IMG, IMG, device=device, generator=torch.Generator(device=device).manual_seed(99 + rank))
-    mask = torch.ones(B, L, S)
-    pad = rs.randint(0, 384, (B, L))
+    gen = torch.Generator(device=device).manual_seed(99 + rank)
+    if MODEL == "meant_vision":
+        images = torch.randn(B, 1, C, IMG, IMG, device=device, generator=gen)
+        target = torch.from_numpy(rs.randint(0, ncls, (B,)).astype("int64")).to(device)
+        return (images,), target
+    tweets = torch.from_numpy(rs.randint(0, V, (B, lag, S)).astype("int64")).to(device)
+    images = torch.randn(B, lag, C, IMG, IMG, device=device, generator=gen)
+    mask = torch.ones(B, lag, S)
+    pad = rs.randint(0, 384, (B, lag))
     for b in range(B):
-        for l in range(L):
+        for l in range(lag):
             if pad[b, l]:
                 mask[b, l, S - pad[b, l]:] = 0
-    target = torch.from_numpy(rs.randint(0, NCLS, (B,)).astype("int64")).to(device)
-    return tweets, images, mask.to(device), target
+    target = torch.from_numpy(rs.randint(0, ncls, (B,)).astype("int64")).to(device)
+    if MODEL == "meant_vqa":            # no lag axis (meant/meant_vqa.py:205)
+        tweets, images, mask = tweets[:, 0], images[:, 0], mask[:, 0]
+    return (tweets, images, mask.to(device)), target
 
 
 def cpu_baseline(E: int):
-    """the oracle on the host cores: C3 config, fp32 eager, eval mode, fwd + CE + bwd.  SURVEY 8(d): batch 1 and batch 8
+    """the oracle on the host cores: same config, fp32 eager, eval mode, fwd + CE + bwd.  SURVEY 8(d): batch 1 and batch 8
     on the box's threads (16 for a 1-GPU box), and batch 1 on a single thread.  Bounded: ~30 s in all."""
     from oracle import meant_oracle as O
     torch.manual_seed(0)
     cores = min(os.cpu_count() or 1, 16)            # the 1-GPU box gives a 16-thread CPU share
-    m = O.meant(D, D, 4, IMG, IMG, P, L, NCLS, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C).eval()
+    lag, s, n, ncls, _ = _shape()
+    if MODEL == "meant":
+        m = O.meant(D, D, 4, IMG, IMG, P, L, NCLS, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C)
+    elif MODEL == "meant_vqa":
+        m = O.meant_vqa(D, D, 4, IMG, IMG, P, 1, 3129, torch.nn.Embedding(V, D), num_heads=H, num_encoders=E, channels=C)
+    else:
+        m = O.meant_vision(D, 4, IMG, IMG, P, 1, NCLS, num_heads=H, num_encoders=E, channels=C)
+    m = m.eval()
     O.fill_weights_(m, 1234)
     rs = np.random.RandomState(99)
 
     def run(B, threads, warm, reps):
         torch.set_num_threads(threads)
-        ids = torch.from_numpy(rs.randint(0, V, (B, L, S)).astype("int64"))
-        img = torch.from_numpy(rs.standard_normal((B, L, C, IMG, IMG)).astype("float32"))
-        mask = torch.ones(B, L, S)
+        ids = torch.from_numpy(rs.randint(0, V, (B, lag, S)).astype("int64"))
+        img = torch.from_numpy(rs.standard_normal((B, lag, C, IMG, IMG)).astype("float32"))
+        mask = torch.ones(B, lag, S)
         mask[:, :, 400:] = 0
-        tgt = torch.from_numpy(rs.randint(0, NCLS, (B,)).astype("int64"))
+        tgt = torch.from_numpy(rs.randint(0, ncls, (B,)).astype("int64"))
+        inputs = {"meant": (ids, img, mask), "meant_vqa": (ids[:, 0], img[:, 0], mask[:, 0]), "meant_vision": (img,)}[MODEL]
         times = []
         for it in range(warm + reps):
             t0 = time.time()
             m.zero_grad(set_to_none=True)
-            O.cross_entropy_on_probs(m(ids, img, mask), tgt).backward()
+            O.cross_entropy_on_probs(m(*inputs), tgt).backward()
             if it >= warm:
                 times.append(time.time() - t0)
         return B / float(np.median(times)), len(times)
 
-    v1, n1 = run(1, cores, 2, 5)
-    v8, n8 = run(8, cores, 1, 2)
-    vs, ns = run(1, 1, 1, 2)
+    small = MODEL != "meant"                        # a twelfth of the work per sample: more repetitions fit the same bound
+    v1, n1 = run(1, cores, 2, 15 if small else 5)
+    v8, n8 = run(8, cores, 1, 6 if small else 2)
+    vs, ns = run(1, 1, 1, 6 if small else 2)
     return {"value": round(v1, 4), "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"CPU oracle (fp32 eager restatement pinned to the reference's golden vectors), same MEANT config "
-                      f"(lag=12, d=768, S=512, 224x224, E={E}), batch 1, fwd+CE+bwd, median of {n1} iterations after 2 warm-ups",
+            "sample": f"CPU oracle (fp32 eager restatement pinned to the reference's golden vectors), same {MODEL} config "
+                      f"(lag={lag}, d=768, S=512, 224x224, E={E}), batch 1, fwd+CE+bwd, median of {n1} iterations after 2 warm-ups",
             "batch8": {"value": round(v8, 4), "cores": int(cores), "sample": f"same, batch 8, median of {n8} after 1 warm-up"},
             "single_thread": {"value": round(vs, 4), "cores": 1, "sample": f"same, batch 1 on one thread, median of {ns} after 1 warm-up"}}
 
@@ -259,7 +305,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=128)
+    ap.add_argument("--model", choices=["meant", "meant_vqa", "meant_vision"], default="meant",
+                    help="meant = BASELINE.json configs[2]/[3] (the headline); meant_vqa = configs[4]; meant_vision = configs[1]")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="samples per GPU (default: 128; meant_vision: 256)")
     ap.add_argument("--encoders", type=int, default=1)
     ap.add_argument("--heads", type=int, default=12, help="attention heads (12 = BASELINE.json; 8 = the reference classes' default, head dim 96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,8 +322,10 @@ def main():
                     help="also time the step fed by meant_amd.data.DeviceBatchLoader from host arrays of this pixel type "
                          "(PCIe-inclusive secondary figure, never `value`)")
     args = ap.parse_args()
-    global H
-    H = args.heads
+    global H, MODEL
+    H, MODEL = args.heads, args.model
+    if args.batch_per_gpu <= 0:
+        args.batch_per_gpu = 256 if MODEL == "meant_vision" else 128
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -316,16 +366,26 @@ def main():
     if world > 1:                                   # identical replicas: broadcast rank 0's weights once
         for p in model.parameters():
             dist.broadcast(p.data, 0)
+    # the dropout seeds are drawn from torch's CPU generator (meant_amd.modules._seed): every rank gets its own stream of
+    # masks, as independent replicas of nn.Dropout would have
+    torch.manual_seed(1234 + rank)
     reducer = GradReducer(model.parameters(), bucket_mb=64.0, direct_grads=True)
-    tweets, images, mask, target = make_batch(B, rank, dev)
+    inputs, target = make_batch(B, rank, dev)
+    step_events = []
 
     def step():
         reducer.prepare()
-        out = model(tweets, images, mask)
+        out = model(*inputs)
         loss = cross_entropy_on_probs(out, target)          # CE on the probabilities, as in_loop_train.py:232
         loss.backward()
         reducer.wait()
+        if step_events is not None and timer.enabled and not iso:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append(ev)
         return loss
+
+    iso = False
 
     def barrier():
         if world > 1:
@@ -338,11 +398,17 @@ def main():
     import meant_amd.modules as _mm
     timer.enabled = True
     timer.others_enabled = not _mm.TWO_STREAMS           # one stream: the timed steps themselves serve for every kernel
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-step durations from one HIP event per step on the main stream (no host sync inside the timed region): the median
+    # beside the mean
+    marks = [ev0] + step_events
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
     timer.enabled = timer.others_enabled = False
     # The timed region runs the two encoder stacks on two HIP streams, so a launch of the dominant kernel shares the
     # CUs with whatever the other stream is running and its event-to-event time is not the kernel's own.  For the
@@ -351,6 +417,7 @@ def main():
     overlapped_recs, iso_steps = timer.recs, 0
     if _mm.TWO_STREAMS:                             # every rank: the step holds the gradient collective
         timer.recs, timer.other, iso_steps = [], [], min(args.steps, 4)
+        iso = True
         _mm.TWO_STREAMS = False
         step()
         torch.cuda.synchronize()
@@ -386,11 +453,11 @@ def main():
         model.eval()
         with torch.no_grad():
             for _ in range(2):
-                model(tweets, images, mask)
+                model(*inputs)
             barrier()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                out = model(tweets, images, mask)
+                out = model(*inputs)
             barrier()
             fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
         assert torch.isfinite(out).all().item()
@@ -400,6 +467,7 @@ def main():
     # loader (gather into pinned memory, H2D on its own stream, conversion + normalisation + patchify on the device)
     host_ms = None
     if args.from_host is not None:
+        assert MODEL == "meant", "--from-host feeds the lagged (graphs, tweets, masks) data set of in_loop_train.py: --model meant only"
         from meant_amd.data import DeviceBatchLoader
         nbatch = 3 + args.steps
         npdt = {"f64": np.float64, "f32": np.float32, "u8": np.uint8}[args.from_host]
@@ -441,7 +509,7 @@ def main():
         sps = world * B * args.steps / elapsed
         n, gf, gt = timer.summary()
         achieved = gf / gt / 1e12 if gt > 0 else 0.0
-        traffic = timer.traffic_per_launch() if B == 128 else None        # the PMC table was taken at 128 samples per GPU
+        traffic = timer.traffic_per_launch() if (B == 128 and MODEL == "meant") else None   # the PMC table holds the headline's shapes
         roofline = {"kernel": "gemm_bf16_nt256s_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic),
@@ -456,11 +524,20 @@ def main():
             roofline["timed_in"] = f"{iso_steps} extra single-stream steps after the timed region"
             roofline["achieved_while_sharing_cus_with_second_stream"] = round(gf2 / gt2 / 1e12, 1) if gt2 > 0 else None
         roofline["others"] = timer.others_summary()
-        res = {"metric": "samples/sec fwd+bwd, MEANT lag=12 d=768", "value": round(sps, 2), "unit": "samples/s",
+        lag_, s_, n_, ncls_, _ = _shape()
+        metric = {"meant": "samples/sec fwd+bwd, MEANT lag=12 d=768", "meant_vqa": "samples/sec fwd+bwd, meant_vqa d=768 seq=512",
+                  "meant_vision": "samples/sec fwd+bwd, meant_vision lag=1 d=768"}[MODEL]
+        workload = {"meant": f"full MEANT (tweet+image) fwd+CE+bwd, lag=12, d=768, {H} heads, seq=512, 224x224 p=16, E={E}, vocab 64001 "
+                             f"(BASELINE.json configs[2]/[3])",
+                    "meant_vqa": f"meant_vqa (image+text, no lag axis) fwd+CE+bwd, d=768, {H} heads, seq=512, 224x224 p=16, E={E}, vocab 64001, "
+                                 f"3129 classes (BASELINE.json configs[4])",
+                    "meant_vision": f"meant_vision (images only) fwd+CE+bwd, lag=1, d=768, {H} heads, 224x224 p=16, E={E} "
+                                    f"(BASELINE.json configs[1])"}[MODEL]
+        res = {"metric": metric, "value": round(sps, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"full MEANT (tweet+image) fwd+CE+bwd, lag=12, d=768, {H} heads, seq=512, 224x224 p=16, "
-                                      f"E={E}, vocab 64001 (BASELINE.json configs[2]/[3])",
+               "config": {"workload": workload,
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                           "train_mode_dropout": not args.eval_mode, "activation_checkpointing": True if args.checkpoint else (int(args.checkpoint_layers) or False), "grad_allreduce": reducer.active,
                           "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1),

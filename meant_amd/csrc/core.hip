@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
-#include <unordered_set>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
 
@@ -31,7 +31,7 @@ extern "C" int meant_version(void) { return 200; /* 0.2.0 */ }
 namespace {
 struct DeviceState {
   int cus = -1;                                   // -1: not queried yet
-  std::unordered_set<const void*> lds_raised;     // kernels whose MaxDynamicSharedMemorySize was set on this device
+  std::unordered_map<const void*, int> lds_raised; // kernel -> the MaxDynamicSharedMemorySize it was raised to on this device
 };
 std::mutex g_dev_mu;
 DeviceState g_dev[MEANT_MAX_DEVICES];
@@ -60,11 +60,12 @@ int meant_raise_dyn_lds(const void* kernel, int bytes) {
   MEANT_REQUIRE(dev >= 0, MEANT_ERR_LAUNCH, "no current HIP device (or device index >= %d)", MEANT_MAX_DEVICES);
   std::lock_guard<std::mutex> lock(g_dev_mu);
   DeviceState& st = g_dev[dev];
-  if (st.lds_raised.count(kernel)) return MEANT_OK;
+  const auto it = st.lds_raised.find(kernel);
+  if (it != st.lds_raised.end() && it->second >= bytes) return MEANT_OK;    // a later, larger request raises it again
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   MEANT_REQUIRE(e == hipSuccess, MEANT_ERR_LAUNCH, "hipFuncSetAttribute(%d bytes of LDS) failed on device %d: %s", bytes, dev,
                 hipGetErrorString(e));
-  st.lds_raised.insert(kernel);
+  st.lds_raised[kernel] = bytes;
   return MEANT_OK;
 }
 
@@ -75,7 +76,7 @@ struct OptionDef { const char* name; const char* env; int dflt; };
 const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"nt_stream", "MEANT_NT_STREAM", 1},           // 0: one-tile-per-workgroup 256x256 NT kernel instead of the streaming one
     {"nt_dynamic", "MEANT_NT_DYNAMIC", 1},         // 0: fixed persistent tile walk; 1: per-XCD counters; 2: draw but ignore (lab); 3: steal-only (tests)
-    {"deterministic", "MEANT_DETERMINISTIC", 0},   // 1: parameter gradients are bit-reproducible (ordered reductions, no float atomics)
+    {"deterministic", "MEANT_DETERMINISTIC", 0},   // 1: dW / dbias, the embedding gradient (d % 8 == 0, d <= 1024) and the norm gains are bit-reproducible (ordered reductions, no float atomics)
     {"nt_grid_cap", "MEANT_NT_GRID_CAP", 0},       // tests: cap the streaming GEMM's grid (0 = one workgroup per CU)
     {"attn_short", "MEANT_ATTN_SHORT", 1},         // 0: sequences of <= 16 tokens take the tiled flash kernels instead of attn_short.hip
     {"nt_ragged", "MEANT_NT_RAGGED", 1},           // 0: ragged M as streaming head + 128 x 128 tail launch instead of the overlapped last row tile

@@ -331,11 +331,10 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
                                                                            float eps, float drop_p, uint64_t seed,
                                                                            const T* __restrict__ dres, const T* __restrict__ gelu_pre,
                                                                            int group_rows) {
-  __shared__ float red[MAXC * 512];                    // per-block gain-gradient columns (d <= 2048)
+  __shared__ float red[4][C * 64 * 8];                 // per wave: the gain-gradient sums of its C * 64 chunks
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float inv_group = BC ? 1.0f / (float)group_rows : 0.f;
   const int nchunk = d >> 3;
-  for (int j = threadIdx.x; j < d; j += NORM_THREADS) red[j] = 0.f;
   int rsel[C], col[C];
   f32x4 g0[C], g1[C];
   float gacc[C][8];
@@ -420,13 +419,19 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
       store8s<T>(dx + off + (lane + 64 * c) * 8, o);
     }
   }
-  __syncthreads();
+  // fixed-order combine (no atomics: the gain gradient is bit-reproducible): chunk k = lane + 64 c of wave w holds column
+  // (k mod nchunk) * 8 of row k / nchunk of the wave's R-row steps
 #pragma unroll
   for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&red[col[c] + i], gacc[c][i]);
+    for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * c) * 8 + i] = gacc[c][i];
   __syncthreads();
-  for (int j = threadIdx.x; j < d; j += NORM_THREADS) partial[(int64_t)blockIdx.x * d + j] = red[j];
+  for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int r = 0; r < R; ++r) s += red[w][r * d + j];
+    partial[(int64_t)blockIdx.x * d + j] = s;
+  }
 }
 
 // rows per wave R and chunks per lane C of the packed kernels, or R = 0 if the shape does not pack

@@ -246,6 +246,7 @@ class _LinearPre(torch.autograd.Function):
         bias_f = _c(bias.detach().float()) if bias is not None else None
         y, pre = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_GELU, True)
         ctx.weight, ctx.bias, ctx.has_bias, ctx.in_shape = weight, bias, bias is not None, shp
+        _claim(weight, "linear"); _claim(bias, "linear")
         ctx.save_for_backward(x2)
         N = weight.shape[0]
         yv, pv = y.view(*shp[:-1], N), pre.view(*shp[:-1], N)
@@ -421,12 +422,33 @@ def _bwd_dw(dy2, x2, dw, db):
 
 
 # Gradient sinks: a gradient reducer (meant_amd.parallel.GradReducer(direct_grads=True)) registers, per parameter, the
-# view of its flat bucket that IS the parameter's .grad and a callback.  A Linear whose weight (and bias) have a sink
-# accumulates dW / db straight into those views -- the C ABI's contract is "+=" -- and reports to the callback, instead of
-# handing autograd a freshly zeroed tensor that AccumulateGrad then adds to the same view with one more launch each
-# (~100 small fills and adds per step).  Valid for parameters that one autograd node produces per backward; the reducer
-# raises if a parameter reports twice.
+# view of its flat bucket that IS the parameter's .grad.  A Linear whose weight (and bias) have a sink accumulates dW / db
+# straight into those views -- the C ABI's contract is "+=" -- and reports to the reducer, instead of handing autograd a
+# freshly zeroed tensor that AccumulateGrad then adds to the same view with one more launch each (~100 small fills and adds
+# per step).  A sink may only be used when ONE kind of consumer produces the parameter's gradient in a backward pass: a
+# parameter that two different ops read (the tied word embedding / vocabulary decoder of the MLM pretrainer,
+# pretrain_mlm.py:318-319) gets one contribution early and one late, and a report from the first would start the bucket's
+# all-reduce before the second has landed.  Every op that reads a parameter therefore CLAIMS it in forward
+# (`_claim(param, site)`); in backward a sink is handed out only if no other site claimed the parameter since the reducer's
+# last `prepare()`, otherwise the op returns its gradient to autograd, whose AccumulateGrad node runs after all
+# contributions and fires the reducer's ordinary hook.  (Recomputation under activation checkpointing claims the same site
+# again, which is fine.)  Two calls of the SAME op kind on one parameter still report twice and raise in the reducer.
 grad_sinks = {}
+
+
+class GradSink:
+    """one parameter's gradient sink: weak references to the parameter and to the reducer that owns the bucket (so that
+    neither is kept alive by this table), the bucket view that is the parameter's .grad, and the sites that claimed the
+    parameter in the current step"""
+    __slots__ = ("param", "view", "reducer", "sites")
+
+    def __init__(self, param, view, reducer):
+        self.param, self.view, self.reducer, self.sites = weakref.ref(param), view, weakref.ref(reducer), set()
+
+    def report(self, p):
+        r = self.reducer()
+        if r is not None:
+            r._sink_report(p)
 
 
 def _lib_option(name: str) -> int:
@@ -434,14 +456,26 @@ def _lib_option(name: str) -> int:
     return _lib.get_option(name)
 
 
-def _sink_of(param):
+def _claim(param, site: str):
+    """forward side of the sink protocol: remember that an op of kind `site` reads `param` in this step"""
+    if grad_sinks and param is not None and torch.is_grad_enabled():
+        ent = grad_sinks.get(id(param))
+        if ent is not None and ent.param() is param:
+            ent.sites.add(site)
+
+
+def _sink_of(param, site: str):
+    """the parameter's sink, or None if it has none, its reducer is gone, or another kind of op also reads the parameter
+    in this step (then the gradient must go through autograd's accumulation)"""
     ent = grad_sinks.get(id(param))
-    if ent is None or ent[0]() is not param:
+    if ent is None or ent.param() is not param or ent.reducer() is None:
+        return None
+    if ent.sites and ent.sites != {site}:
         return None
     return ent
 
 
-def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0, bias_param=None):
+def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0, bias_param=None, site="linear"):
     """returns dx2 (or None), dW [sum N_i (+ pad_rows), K] fp32, db [same] fp32 or None; dW / db are None when they went
     straight into the parameters' gradient sinks"""
     M, N = dy2.shape
@@ -451,13 +485,13 @@ def _linear_bwd_raw(dy2, x2, params, need_dx, has_bias, pad_rows=0, bias_param=N
         wT = weights.get(params, dy2.dtype, True, pad_rows)             # [K, N]
         dx = torch.empty((M, K), device=dy2.device, dtype=dy2.dtype)
         check(lib.meant_linear_bwd_dx(_p(dy2), dy2.stride(0), _p(wT), _p(dx), K, M, N, K, _dt(dy2), _stream()), "linear_bwd_dx")
-    if len(params) == 1 and pad_rows == 0 and grad_sinks:
-        ws_, bs_ = _sink_of(params[0]), (_sink_of(bias_param) if has_bias else None)
-        if ws_ is not None and (not has_bias or bs_ is not None) and ws_[1].shape == (N, K) and ws_[1].is_contiguous():
-            _bwd_dw(dy2, x2, ws_[1], bs_[1] if has_bias else None)
-            ws_[2](params[0])
+    if len(params) == 1 and pad_rows == 0 and grad_sinks and (bias_param is not None or not has_bias):
+        ws_, bs_ = _sink_of(params[0], site), (_sink_of(bias_param, site) if has_bias else None)
+        if ws_ is not None and (not has_bias or bs_ is not None) and ws_.view.shape == (N, K) and ws_.view.is_contiguous():
+            _bwd_dw(dy2, x2, ws_.view, bs_.view if has_bias else None)
+            ws_.report(params[0])
             if has_bias:
-                bs_[2](bias_param)
+                bs_.report(bias_param)
             return dx, None, None
     dw = torch.zeros((N, K), device=dy2.device, dtype=torch.float32)
     db = torch.zeros(N, device=dy2.device, dtype=torch.float32) if has_bias else None
@@ -482,6 +516,7 @@ class _Linear(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.weight, ctx.bias = weight, bias
+        _claim(weight, "linear"); _claim(bias, "linear")
         ctx.save_for_backward(x2, pre if (epilogue & EPI_GELU) else (y if (epilogue & EPI_SIGMOID) else None))
         ctx.in_shape = shp
         return y.view(*shp[:-1], weight.shape[0])
@@ -947,6 +982,7 @@ class _Embedding(torch.autograd.Function):
         ctx.save_for_backward(ids_c)
         ctx.meta = (V, d)
         ctx.table = table                                # the Parameter itself: its gradient sink, if any, is looked up in backward
+        _claim(table, "embedding")
         return out
 
     @staticmethod
@@ -956,10 +992,11 @@ class _Embedding(torch.autograd.Function):
         dout = _c(dout)
         # with a gradient sink (GradReducer(direct_grads=True)) the rows are summed straight into the reducer's bucket view:
         # no [V, d] zeros + autograd add per step (0.8 GB of traffic at V = 64001)
-        sink = _sink_of(ctx.table) if grad_sinks else None
-        if sink is not None and (sink[1].shape != (V, d) or not sink[1].is_contiguous()):
+        # (not when another op reads the table as well -- the tied vocabulary decoder: see grad_sinks)
+        sink = _sink_of(ctx.table, "embedding") if grad_sinks else None
+        if sink is not None and (sink.view.shape != (V, d) or not sink.view.is_contiguous()):
             sink = None
-        dtab = sink[1] if sink is not None else torch.zeros((V, d), device=dout.device, dtype=torch.float32)
+        dtab = sink.view if sink is not None else torch.zeros((V, d), device=dout.device, dtype=torch.float32)
         n = ids_c.numel()
         if d <= 1024 and d % 8 == 0 and (n >= 4096 or _lib_option("deterministic")):   # the other kernel is float atomics per token
             # index preparation (a sort of the token ids) is host-side plumbing; the reduction itself is the HIP kernel
@@ -969,7 +1006,7 @@ class _Embedding(torch.autograd.Function):
         else:
             check(lib.meant_embedding_bwd(_p(dout), _p(ids_c), _p(dtab), n, d, V, _dt(dout), _stream()), "embedding_bwd")
         if sink is not None:
-            sink[2](ctx.table)
+            sink.report(ctx.table)
             return None, None, None
         return None, dtab, None
 
@@ -1044,7 +1081,8 @@ class _VocabLinear(torch.autograd.Function):
         if bias is not None:
             bias_f = _c(torch.nn.functional.pad(bias.detach().float(), (0, Vp - V)))
         y, _ = _linear_fwd_raw(x2, w_c, bias_f, None, EPI_NONE, False)
-        ctx.weight, ctx.has_bias, ctx.in_shape, ctx.V = weight, bias is not None, shp, V
+        ctx.weight, ctx.bias, ctx.has_bias, ctx.in_shape, ctx.V = weight, bias, bias is not None, shp, V
+        _claim(weight, "vocab"); _claim(bias, "vocab")
         ctx.save_for_backward(x2)
         return y.view(*shp[:-1], Vp)
 
@@ -1054,8 +1092,11 @@ class _VocabLinear(torch.autograd.Function):
         V = ctx.V
         Vp = dy.shape[-1]
         dy2 = _c(dy).view(-1, Vp)
-        dx, dw, db = _linear_bwd_raw(dy2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias, pad_rows=Vp - V)
-        return (dx.view(ctx.in_shape) if dx is not None else None), dw[:V], (db[:V] if db is not None else None)
+        # V a multiple of 256: nothing is padded and the gradients may go straight into the parameters' sinks (dw, db None)
+        dx, dw, db = _linear_bwd_raw(dy2, x2, (ctx.weight,), ctx.needs_input_grad[0], ctx.has_bias, pad_rows=Vp - V,
+                                     bias_param=ctx.bias, site="vocab")
+        return ((dx.view(ctx.in_shape) if dx is not None else None), (dw[:V] if dw is not None else None),
+                (db[:V] if db is not None else None))
 
 
 def _vocab_logits_padded(x, weight, bias):

@@ -42,10 +42,14 @@ class _Bucket:
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None,
                  average: bool = True, direct_grads: bool = False):
-        """direct_grads: let the Linear backward write dW / db straight into the bucket views (meant_amd.ops.grad_sinks)
-        instead of returning fresh tensors for autograd to add to them.  Requires every such parameter to be used by one
-        autograd node per backward pass (true for the MEANT models: no weight sharing between Linears); a parameter that
-        reports twice in one step raises."""
+        """direct_grads: let the Linear / embedding backward write dW / db straight into the bucket views
+        (meant_amd.ops.grad_sinks) instead of returning fresh tensors for autograd to add to them.  A parameter that two
+        different kinds of op read in one step (a word embedding tied to the vocabulary decoder) is detected in forward
+        and keeps autograd's accumulation; two Linears sharing one weight report twice and raise.  With direct_grads a
+        backward pass ACCUMULATES into the buckets and counts every parameter once per `prepare()`: for gradient
+        accumulation over micro-batches run all but the last backward under `no_sync()`.  `torch.autograd.grad` on a
+        parameter with a sink returns None (its gradient went into the bucket).  A parameter belongs to one reducer at a
+        time: constructing a second reducer over it closes the first."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -89,12 +93,23 @@ class GradReducer:
         flush()
         self._owner = {}
         self._launch_streams = {}
+        self._hooks = []
+        self._sync = True
+        self._closed = False
+        import weakref
+        wself = weakref.ref(self)            # the parameters must not keep the reducer (and its buckets) alive through their hooks
+
+        def hook(p, _w=wself):
+            r = _w()
+            if r is not None:
+                r._hook(p)
         for b in self.buckets:
             for p in b.params:
                 self._owner[id(p)] = b
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
         self.direct_grads = direct_grads
         self._reported = set()
+        self._sink_ids = []
         self.prepare()
         if direct_grads:
             self._register_sinks()
@@ -105,19 +120,71 @@ class GradReducer:
         for b in self.buckets:
             for p, off in zip(b.params, b.offsets):
                 if p.is_cuda:
+                    old = ops.grad_sinks.get(id(p))
+                    if old is not None and old.param() is p:
+                        prev = old.reducer()
+                        if prev is not None and prev is not self:
+                            prev.close()                 # its hooks and sinks would otherwise keep firing on our parameters
                     view = b.flat[off:off + p.numel()].view_as(p)
-                    ops.grad_sinks[id(p)] = (weakref.ref(p), view, self._sink_report)
+                    ops.grad_sinks[id(p)] = ops.GradSink(p, view, self)
+                    self._sink_ids.append(id(p))
                     weakref.finalize(p, ops.grad_sinks.pop, id(p), None)
+        # the table holds only weak references to this reducer; when it is collected its entries go with it
+        weakref.finalize(self, GradReducer._drop_sinks, list(self._sink_ids))
 
-    # -- per step ---------------------------------------------------------------------------
-    def prepare(self):
-        """zero the buckets (== zero_grad) and re-arm the hooks; call before each backward"""
+    @staticmethod
+    def _drop_sinks(ids, owner=None):
+        from . import ops
+        for i in ids:
+            ent = ops.grad_sinks.get(i)
+            if ent is not None and (ent.reducer() is None or ent.reducer() is owner):
+                ops.grad_sinks.pop(i, None)
+
+    def close(self):
+        """detach from the parameters: remove the autograd hooks and the gradient sinks (the .grad views stay valid)"""
+        if self._closed:
+            return
+        self._closed = True
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        GradReducer._drop_sinks(self._sink_ids, self)
+        self._sink_ids = []
+
+    def no_sync(self):
+        """context manager for gradient accumulation (as DistributedDataParallel.no_sync): backward passes inside it add
+        into the buckets but neither count parameters nor start collectives; the first backward after it reduces the
+        accumulated sums.  Do not call prepare() between the micro-batches (it zeroes the buckets)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = prev
+                self._rearm()
+        return ctx()
+
+    def _rearm(self):
+        from . import ops
         self._reported.clear()
         for b in self.buckets:
-            b.flat.zero_()
             b.pending = len(b.params)
             b.handle = None
             b.streams = []
+        for i in self._sink_ids:
+            ent = ops.grad_sinks.get(i)
+            if ent is not None:
+                ent.sites.clear()
+
+    # -- per step ---------------------------------------------------------------------------
+    def prepare(self):
+        """zero the buckets (== zero_grad) and re-arm the hooks; call before each forward"""
+        self._rearm()
+        for b in self.buckets:
+            b.flat.zero_()
             for p, off in zip(b.params, b.offsets):  # keep .grad pointing into the bucket
                 n = p.numel()
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * 4:
@@ -125,6 +192,8 @@ class GradReducer:
 
     def _sink_report(self, p):
         """called by a backward that accumulated this parameter's gradient straight into its bucket view"""
+        if not self._sync:
+            return
         if id(p) in self._reported:
             raise RuntimeError(f"GradReducer(direct_grads=True): a parameter of shape {tuple(p.shape)} received its gradient twice "
                                "in one backward pass (shared weights?); construct the reducer with direct_grads=False")
@@ -133,7 +202,7 @@ class GradReducer:
 
     def _hook(self, p):
         """autograd's post-accumulate hook; a parameter whose gradient went through its sink has been counted already"""
-        if id(p) in self._reported:
+        if not self._sync or id(p) in self._reported:
             return
         self._count(p)
 

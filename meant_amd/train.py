@@ -136,9 +136,12 @@ class TrainStep:
     """forward -> CE on probabilities -> backward (+ overlapped gradient all-reduce) -> clip + AdamW."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 5e-5, weight_decay: float = 1e-2, max_grad_norm: float = 1.0,
-                 bucket_mb: float = 64.0):
+                 bucket_mb: float = 64.0, direct_grads: bool = True):
+        """direct_grads (GradReducer): parameter gradients are accumulated straight into the flat buckets by the backward
+        kernels; pass False if the model's parameters are also differentiated outside this step (torch.autograd.grad,
+        several backward passes per optimizer step without reducer.no_sync())"""
         self.model = model
-        self.reducer = GradReducer(model.parameters(), bucket_mb=bucket_mb, direct_grads=True)
+        self.reducer = GradReducer(model.parameters(), bucket_mb=bucket_mb, direct_grads=direct_grads)
         self.opt = FusedAdamW(self.reducer, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
 
     def __call__(self, *inputs, target):

@@ -226,3 +226,185 @@ def test_two_ranks_share_one_gpu_reduced_grads_equal_single_process(dev, tmp_pat
         ref = p.grad.detach().float().cpu()
         # bf16 tier: the two half-batches round differently from the whole batch only in the last bits of the fp32 sums
         assert (got[k] - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-4), k
+
+
+# ---- bench.py as the driver launches it ----------------------------------------------------------------------------------
+def _run_bench(argv, env_extra, nproc=1, port="29561", timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(root, "bench.py"), "--gpus", str(nproc)] + argv
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + argv
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_prints_one_contract_line(dev):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it, both
+    ranks on GPU 0 over gloo (a one-GPU box cannot give RCCL two devices): one JSON line from rank 0 with the contract's
+    fields, the whole-job batch, the gradient collective live"""
+    res = _run_bench(["--batch-per-gpu", "2", "--steps", "2", "--warmup", "1"],
+                     {"MEANT_DIST_BACKEND": "gloo", "MEANT_ALL_RANKS_ON_GPU0": "1"}, nproc=2)
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["config"]["grad_allreduce"] is True and res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert res["unit"] == "samples/s" and res["scaling"] == "weak" and res["higher_is_better"] is True and res["dtype"] == "bf16"
+    assert np.isfinite(res["value"]) and res["value"] > 0
+    assert abs(res["value"] - 4 / res["ms_per_step"] * 1e3) <= 0.01 * res["value"]
+    assert "roofline" in res and "cpu_baseline" not in res          # the CPU leg runs at N = 1 only
+
+
+@pytest.mark.parametrize("model,batch", [("meant_vqa", 4), ("meant_vision", 8)])
+def test_bench_other_configs_print_the_contract_line(dev, model, batch):
+    """BASELINE.json configs[4] (meant_vqa) and configs[1] (meant_vision) through bench.py --model: same contract"""
+    res = _run_bench(["--model", model, "--batch-per-gpu", str(batch), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert res["n_gpus"] == 1 and model in res["metric"] and model in res["config"]["workload"]
+    assert res["config"]["batch_per_gpu"] == batch and np.isfinite(res["value"]) and res["value"] > 0
+    assert res["ms_per_step_median"] > 0 and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(res["roofline"])
+
+
+# ---- gradient sinks and shared parameters (ADVICE r2) ------------------------------------------------------------------------
+_TIED_TWO_RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MEANT_REPO"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from meant_amd import ops
+from meant_amd.parallel import GradReducer
+V, d = int(os.environ["MEANT_V"]), 128
+torch.manual_seed(0)
+emb = torch.nn.Embedding(V, d).cuda()
+lin = torch.nn.Linear(d, d).cuda()
+g = torch.Generator().manual_seed(5)
+ids = torch.randint(0, V, (2 * 4096,), generator=g).view(2, 4096)[rank].cuda()
+tgt = torch.randint(0, V, (2 * 4096,), generator=g).view(2, 4096)[rank].cuda()
+params = list(emb.parameters()) + list(lin.parameters())
+red = GradReducer(params, bucket_mb=64.0, direct_grads=True)
+for _ in range(2):
+    red.prepare()
+    x = ops.embedding(ids, emb.weight, torch.bfloat16)                     # the table read by the gather ...
+    h = ops.linear(x, lin.weight, lin.bias)
+    loss = ops.vocab_linear_cross_entropy(h, emb.weight, None, tgt)        # ... and, tied, by the vocabulary decoder
+    loss.backward()
+    red.wait()
+torch.cuda.synchronize()
+if rank == 0:
+    torch.save({"emb": emb.weight.grad.detach().cpu().clone(), "w": lin.weight.grad.detach().cpu().clone()}, os.environ["MEANT_OUT"])
+dist.barrier()
+dist.destroy_process_group()
+print("TIED_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("V", [1000, 1024])
+def test_tied_embedding_and_vocab_decoder_reduce_both_contributions(dev, tmp_path, V):
+    """a word embedding tied to the vocabulary decoder (pretrain_mlm.py:318-319) under GradReducer(direct_grads=True) on two
+    ranks: the table's gradient has an early contribution (decoder) and a late one (gather); neither may start the
+    bucket's all-reduce alone.  V = 1024 is the unpadded case in which the decoder could use a sink as well.  The reduced
+    gradient must equal one process on both shards."""
+    import os
+    import subprocess
+    import sys
+    from meant_amd import ops
+    opath = str(tmp_path / "tied.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
+                   MEANT_REPO=root, MEANT_OUT=opath, MEANT_V=str(V), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TIED_TWO_RANKS], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "TIED_OK" in so, so[-2000:] + se[-4000:]
+    got = torch.load(opath)
+    d = 128
+    torch.manual_seed(0)
+    emb = torch.nn.Embedding(V, d).to(dev)
+    lin = torch.nn.Linear(d, d).to(dev)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (2 * 4096,), generator=g).to(dev)
+    tgt = torch.randint(0, V, (2 * 4096,), generator=g).to(dev)
+    x = ops.embedding(ids, emb.weight, torch.bfloat16)
+    loss = ops.vocab_linear_cross_entropy(ops.linear(x, lin.weight, lin.bias), emb.weight, None, tgt)
+    loss.backward()                                                        # mean over both shards == average of the shard means
+    for k, ref in (("emb", emb.weight.grad), ("w", lin.weight.grad)):
+        ref = ref.float().cpu()
+        assert (got[k] - ref).abs().max().item() <= 5e-3 * ref.abs().max().item(), k
+
+
+def test_vocab_linear_without_padding_under_direct_grads(dev):
+    """V a multiple of 256, bias None, the weight registered with GradReducer(direct_grads=True): dW goes straight into the
+    bucket (the backward used to index a None); with a bias both go there; gradients equal the autograd path's"""
+    from meant_amd import ops
+    from meant_amd.parallel import GradReducer
+    torch.manual_seed(2)
+    V, d, T = 512, 128, 1024
+    x = torch.randn(T, d, device=dev).bfloat16()
+    tgt = torch.randint(0, V, (T,), device=dev)
+    for with_bias in (False, True):
+        w = torch.nn.Parameter(torch.randn(V, d, device=dev) * 0.05)
+        b = torch.nn.Parameter(torch.randn(V, device=dev) * 0.1) if with_bias else None
+        xr = x.clone().requires_grad_()
+        ops.vocab_linear_cross_entropy(xr, w, b, tgt).backward()
+        ref_w, ref_b, ref_x = w.grad.clone(), (b.grad.clone() if with_bias else None), xr.grad.clone()
+        w.grad = None
+        if with_bias:
+            b.grad = None
+        red = GradReducer([w] + ([b] if with_bias else []), direct_grads=True)
+        for _ in range(2):
+            red.prepare()
+            xs = x.clone().requires_grad_()
+            ops.vocab_linear_cross_entropy(xs, w, b, tgt).backward()
+            red.wait()
+            assert (w.grad - ref_w).abs().max().item() <= 1e-5 * ref_w.abs().max().item() + 1e-7
+            assert torch.equal(xs.grad, ref_x)
+            if with_bias:
+                assert (b.grad - ref_b).abs().max().item() <= 1e-5 * ref_b.abs().max().item() + 1e-7
+        red.close()
+        assert id(w) not in ops.grad_sinks
+
+
+def test_grad_reducer_no_sync_accumulates_and_second_reducer_closes_the_first(dev):
+    """gradient accumulation over micro-batches with direct_grads: backward passes under no_sync() add into the buckets
+    without counting; the reducer a second one replaces stops receiving reports"""
+    from meant_amd import ops
+    from meant_amd.parallel import GradReducer
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(128, 128).to(dev)
+    xs = [torch.randn(256, 128, device=dev).bfloat16() for _ in range(3)]
+    ref = None
+    for x in xs:
+        ops.linear(x, lin.weight, lin.bias).float().sum().backward()
+    ref_w, ref_b = lin.weight.grad.clone(), lin.bias.grad.clone()
+    red = GradReducer(lin.parameters(), direct_grads=True)
+    red.prepare()
+    with red.no_sync():
+        for x in xs[:2]:
+            ops.linear(x, lin.weight, lin.bias).float().sum().backward()
+    ops.linear(xs[2], lin.weight, lin.bias).float().sum().backward()
+    red.wait()
+    assert (lin.weight.grad - ref_w).abs().max().item() <= 1e-4 * ref_w.abs().max().item()
+    assert (lin.bias.grad - ref_b).abs().max().item() <= 1e-4 * ref_b.abs().max().item()
+    with pytest.raises(RuntimeError, match="twice"):                       # outside no_sync a second backward is refused, as before
+        ops.linear(xs[0], lin.weight, lin.bias).float().sum().backward()
+    red2 = GradReducer(lin.parameters(), direct_grads=True)
+    assert red._closed and ops.grad_sinks[id(lin.weight)].reducer() is red2
+    red2.prepare()
+    ops.linear(xs[0], lin.weight, lin.bias).float().sum().backward()
+    red2.wait()
+    assert lin.weight.grad.data_ptr() == red2.buckets[0].flat.data_ptr() + red2.buckets[0].offsets[red2.buckets[0].params.index(lin.weight)] * 4
+    del red2
+    import gc
+    gc.collect()
+    assert id(lin.weight) not in ops.grad_sinks                            # the table does not keep a dead reducer's entries
