@@ -124,6 +124,29 @@ int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const void* x, const
                              float drop_p, uint64_t seed, const void* dres, int dres_pooled, const void* gelu_pre,
                              int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- RMSNorm folded into the Linear that consumes it -------- utils/rms_norm.py:40-57 followed by an nn.Linear:
+ *                                                               meant/meant.py:61-63 (encode2[0] -> encode2[1] -> GELU), :103-106
+ * Linear(RMSNorm(x)) = r (x) (x W'^T) + b with W' = W diag(g) and r[m] = 1 / (||x_m|| / sqrt(d) + eps): the normalisation is
+ * a per-row factor in the GEMM epilogue (meant_linear_fwd_rowscale), the gain a column scale of the weight (meant_colscale);
+ * the normalised tensor never exists, forward or backward.  bf16 tier, packed widths (meant_rmsnorm_pooled_ok) only.
+ *   meant_rmsnorm_stats      r[rows] from one read of x.
+ *   meant_rmsnorm_bwd_chain  the backward of the NEXT norm down the layer (the one behind the GELU: meant_rmsnorm_bwd with
+ *                            gelu_pre, token-level dy and the stored activation x; or its pooled form: dy_pooled != 0, x NULL),
+ *                            which is where the gradient dpre of this Linear's output comes from.  In the same pass it also
+ *                            writes dx_scaled = up_rinv[m] * dpre (the operand of both backward GEMMs), kcoef[m] =
+ *                            rowdot(dpre, gelu_pre - up_bias) up_rinv^2 / ((1 - up_eps up_rinv) up_d), up_d the width of the folded norm (see meant_linear_bwd_dx_norm)
+ *                            and dbias_up += column sums of the unscaled dpre (the Linear's bias gradient).
+ *   meant_colscale / _bwd    W' = W diag(g);  dW += dW' diag(g), dg[k] += sum_n dW'[n,k] W[n,k]   (float, [N, K]). */
+int meant_rmsnorm_stats(const void* x, float* rinv, int64_t rows, int64_t d, float eps, int dtype, void* stream);
+int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv,
+                            void* dx_scaled, float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps,
+                            float drop_p, uint64_t seed, const void* gelu_pre, const float* up_rinv, const float* up_bias,
+                            float up_eps, int64_t up_d, float* kcoef, float* dbias_up, int dtype, void* workspace, size_t workspace_bytes,
+                            void* stream);
+int meant_colscale(const float* w, const float* g, float* out, int64_t N, int64_t K, void* stream);
+int meant_colscale_bwd(const float* dwp, const float* w, const float* g, float* dw, float* dg, int64_t N, int64_t K,
+                       void* stream);
+
 /* ---- LayerNorm (heads of meant_vision / meant_tweet) ----- meant/meant_vision.py:147
  * stats: float [rows, 2] (mean, rstd). */
 int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
@@ -145,6 +168,19 @@ int meant_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bia
 int meant_qkv_proj_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* qkv, int64_t M,
                        int64_t K, int64_t S, int H, int Dh, int R, const float* qa, const float* qb,
                        const float* ka, const float* kb, int dtype, void* stream);
+/* Linear with its input RMSNorm folded in (see "RMSNorm folded into the Linear" above).
+ * forward : y = act(row_scale[m] (x w^T) + bias) (+ residual); w = W diag(g) in the act dtype; preact as in meant_linear_fwd.
+ * backward: dx[M,K] = dy_scaled[M,N] w  -  coef[m] x[m,:]  (+ dres) (+ dres_pooled[m / group_rows, :] / group_rows),
+ *           dy_scaled / coef from meant_rmsnorm_bwd_chain; dres: the gradient through the residual branch that shares x
+ *           (act dtype [M,K]); dres_pooled: float [M / group_rows, K], the gradient of the sequence means of x.
+ *           (dW' = dy_scaled^T x through meant_linear_bwd_dw with dbias NULL.) */
+int meant_linear_fwd_rowscale(const void* x, int64_t ldx, const void* w, const float* bias, const float* row_scale,
+                              const void* residual, int64_t ldr, void* y, int64_t ldy, void* preact, int64_t M, int64_t N,
+                              int64_t K, int epilogue, int dtype, void* stream);
+int meant_linear_bwd_dx_norm(const void* dy_scaled, int64_t lddy, const void* wT, const void* x, int64_t ldx,
+                             const float* coef, const void* dres, int64_t lddres, const float* dres_pooled,
+                             int64_t group_rows, void* dx, int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype,
+                             void* stream);
 /* dx[M,K] = dy[M,N] w[N,K]   (wT is w transposed, [K,N], act dtype: see meant_transpose2d) */
 int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, int64_t M,
                         int64_t N, int64_t K, int dtype, void* stream);

@@ -100,6 +100,47 @@ extern "C" int meant_linear_bwd_dx(const void* dy, int64_t lddy, const void* wT,
   return MEANT_ERR_ARG;
 }
 
+// ---- Linear with its input RMSNorm folded in (bf16 tier, MFMA kernels only) ------------------------------------------------
+// forward:  y = act(row_scale[m] (x w^T) + bias) (+ residual), w = W diag(g) (meant_colscale), row_scale = 1 / (rms(x) + eps)
+// (meant_rmsnorm_stats): Linear(RMSNorm(x)) without the normalised tensor ever existing (utils/rms_norm.py:40-57 followed by
+// an nn.Linear, meant/meant.py:59-64).
+extern "C" int meant_linear_fwd_rowscale(const void* x, int64_t ldx, const void* w, const float* bias, const float* row_scale,
+                                         const void* residual, int64_t ldr, void* y, int64_t ldy, void* preact, int64_t M, int64_t N,
+                                         int64_t K, int epilogue, int dtype, void* stream) {
+  MEANT_REQUIRE(x && w && y && row_scale, MEANT_ERR_ARG, "linear_fwd_rowscale: null pointer");
+  MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, MEANT_ERR_ARG, "linear_fwd_rowscale: bad shape");
+  MEANT_REQUIRE(dtype == MEANT_BF16 && bf16_nt_ok(x, ldx, w, K, y, ldy, residual, ldr, K) && (ldy & 7) == 0 && !(epilogue & MEANT_EPI_SIGMOID),
+                MEANT_ERR_UNSUPPORTED, "linear_fwd_rowscale: bf16 tier, K %% 64 == 0, 16-byte aligned rows only");
+  MEANT_REQUIRE(!(epilogue & MEANT_EPI_RESIDUAL) || residual, MEANT_ERR_ARG, "linear_fwd_rowscale: residual epilogue without residual pointer");
+  GemmBf16Args a{};
+  a.A = (const bf16*)x; a.lda = ldx; a.B = (const bf16*)w; a.ldb = K; a.C = (bf16*)y; a.ldc = ldy;
+  a.M = M; a.N = N; a.K = K; a.bias = bias; a.residual = (epilogue & MEANT_EPI_RESIDUAL) ? (const bf16*)residual : nullptr; a.ldr = ldr;
+  a.preact = (bf16*)preact; a.epilogue = epilogue; a.row_scale = row_scale;
+  return gemm_bf16_nt_launch(a, (hipStream_t)stream);
+}
+
+// input gradient of the same:  dx = dy_scaled wT^T - coef[m] x[m, :] (+ dres), dy_scaled = row_scale * dy and coef as produced by
+// meant_rmsnorm_bwd_chain: the RMSNorm backward's own term rides this GEMM's epilogue; no pass of its own.
+extern "C" int meant_linear_bwd_dx_norm(const void* dy_scaled, int64_t lddy, const void* wT, const void* x, int64_t ldx, const float* coef,
+                                        const void* dres, int64_t lddres, const float* dres_pooled, int64_t group_rows, void* dx, int64_t lddx,
+                                        int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+  MEANT_REQUIRE(dy_scaled && wT && x && coef && dx, MEANT_ERR_ARG, "linear_bwd_dx_norm: null pointer");
+  MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && lddx >= K && ldx >= K, MEANT_ERR_ARG, "linear_bwd_dx_norm: bad shape");
+  MEANT_REQUIRE(dtype == MEANT_BF16 && bf16_nt_ok(dy_scaled, lddy, wT, N, dx, lddx, nullptr, 0, N) && (lddx & 7) == 0 && (ldx & 7) == 0 &&
+                meant_aligned16(x) && (!dres || ((lddres & 7) == 0 && meant_aligned16(dres))),
+                MEANT_ERR_UNSUPPORTED, "linear_bwd_dx_norm: bf16 tier, N %% 64 == 0, 16-byte aligned rows only");
+  GemmBf16Args a{};
+  a.A = (const bf16*)dy_scaled; a.lda = lddy; a.B = (const bf16*)wT; a.ldb = N; a.C = (bf16*)dx; a.ldc = lddx;
+  a.M = M; a.N = K; a.K = N;
+  a.residual = (const bf16*)dres; a.ldr = lddres;
+  a.sub = (const bf16*)x; a.ldsub = ldx; a.sub_coef = coef;
+  if (dres_pooled) {                                   // + dres_pooled[m / group_rows, :] / group_rows: the gradient of mean_s(x)
+    MEANT_REQUIRE(group_rows > 0 && M % group_rows == 0 && group_rows < (1LL << 30), MEANT_ERR_ARG, "linear_bwd_dx_norm: bad group_rows");
+    a.bres = dres_pooled; a.bres_rows = (int)group_rows; a.bres_scale = 1.0f / (float)group_rows;
+  }
+  return gemm_bf16_nt_launch(a, (hipStream_t)stream);
+}
+
 extern "C" size_t meant_linear_bwd_dw_ws(int64_t M, int64_t N, int64_t K, int dtype) {
   return dtype == MEANT_BF16 ? gemm_bf16_tn_ws(M, N, K) : 0;
 }

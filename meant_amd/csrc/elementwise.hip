@@ -520,6 +520,49 @@ static int launch_ew2(const void* a, const void* b, void* y, int64_t n, int dtyp
   return MEANT_OK;
 }
 
+// ---- RMSNorm gain folded into the consumer Linear's weight (meant_linear_fwd_rowscale): W'[n, k] = W[n, k] g[k] -----------
+namespace {
+__global__ __launch_bounds__(256) void colscale_kernel(const float* __restrict__ w, const float* __restrict__ g, float* __restrict__ out,
+                                                        int64_t total, int K) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = w[i] * g[i % K];
+}
+// dW[n, k] += dWp[n, k] g[k];  dg[k] += sum_n dWp[n, k] W[n, k].  One block per 64 columns, 4 row phases, ordered combine.
+__global__ __launch_bounds__(256) void colscale_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ w,
+                                                            const float* __restrict__ g, float* __restrict__ dw, float* __restrict__ dg,
+                                                            int N, int K) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (k < K) {
+    const float gk = g[k];
+    for (int n = ph; n < N; n += 4) {
+      const float d = dwp[(int64_t)n * K + k];
+      s += d * w[(int64_t)n * K + k];
+      dw[(int64_t)n * K + k] += d * gk;
+    }
+  }
+  red[ph][c] = s;
+  __syncthreads();
+  if (ph == 0 && k < K) dg[k] += (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+}  // namespace
+
+extern "C" int meant_colscale(const float* w, const float* g, float* out, int64_t N, int64_t K, void* stream) {
+  EW_REQ(w && g && out && N > 0 && K > 0 && N * K < (1LL << 40), "colscale: bad argument");
+  const int64_t total = N * K;
+  const dim3 grid((unsigned)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096));
+  hipLaunchKernelGGL(colscale_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, g, out, total, (int)K);
+  MEANT_LAUNCH_CHECK("colscale");
+  return MEANT_OK;
+}
+extern "C" int meant_colscale_bwd(const float* dwp, const float* w, const float* g, float* dw, float* dg, int64_t N, int64_t K, void* stream) {
+  EW_REQ(dwp && w && g && dw && dg && N > 0 && K > 0 && N < (1LL << 30) && K < (1LL << 30), "colscale_bwd: bad argument");
+  hipLaunchKernelGGL(colscale_bwd_kernel, dim3((unsigned)ceil_div(K, 64)), dim3(256), 0, (hipStream_t)stream, dwp, w, g, dw, dg, (int)N, (int)K);
+  MEANT_LAUNCH_CHECK("colscale_bwd");
+  return MEANT_OK;
+}
+
 extern "C" int meant_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream) {
   return launch_ew2(dy, pre, dx, n, dtype, stream, GeluBwdOp(), "gelu_bwd");
 }

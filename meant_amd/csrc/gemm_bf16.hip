@@ -138,6 +138,18 @@ __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
     }
+    if (a.sub) {
+      const bf16x8 sv = *reinterpret_cast<const bf16x8*>(a.sub + m * a.ldsub + n);
+      const float kc = a.sub_coef[m];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(-kc, (float)sv[e], v[e]);
+    }
+    if (a.bres) {
+      const float* bp = a.bres + (m / a.bres_rows) * a.N + n;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(a.bres_scale, e < 4 ? b0[e] : b1[e - 4], v[e]);
+    }
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
@@ -150,6 +162,8 @@ __device__ __forceinline__ void nt_store_row8(const GemmBf16Args& a, int64_t m, 
       if (a.epilogue & MEANT_EPI_GELU) x = gelu_erf_fast(x);
       if (a.epilogue & MEANT_EPI_SIGMOID) x = 1.f / (1.f + __expf(-x));
       if (a.residual) x += (float)a.residual[m * a.ldr + n + e];
+      if (a.sub) x -= a.sub_coef[m] * (float)a.sub[m * a.ldsub + n + e];
+      if (a.bres) x += a.bres_scale * a.bres[(m / a.bres_rows) * a.N + n + e];
       a.C[m * a.ldc + n + e] = (bf16)x;
     }
   }
@@ -230,8 +244,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Args a, in
     float v[8];
     const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc + 4);
+    const float rs = a.row_scale ? a.row_scale[m] : 1.0f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(e < 4 ? lo[e] : hi[e - 4], rs, bias[e]);
     nt_store_row8(a, m, n, v, vec_ok);
   }
 }
@@ -351,8 +366,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Args a,
       float v[8];
       const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDC + cc + 4);
+      const float rs = a.row_scale ? a.row_scale[m] : 1.0f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? lo[e] : hi[e - 4]) + bias[e];
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(e < 4 ? lo[e] : hi[e - 4], rs, bias[e]);
       nt_store_row8(a, m, n, v, vec_ok);
     }
   }
@@ -403,7 +419,9 @@ struct alignas(64) TileSched {
 constexpr int N_SCHED_SLOTS = 256;
 __device__ TileSched g_tile_sched[N_SCHED_SLOTS];
 
-template <int DBG, bool ROT>
+// EXT: the extended epilogue (GemmBf16Args::row_scale / sub / sub_coef) -- an instantiation of its own so that the plain
+// kernel's register budget (236 of 256) is not touched
+template <int DBG, bool ROT, bool EXT = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a, int ntm, int ntn, TileSched* __restrict__ sched, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -632,20 +650,91 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       // memory round trip per round, +25 % (text) / +38 % (vision) on the residual GEMMs of the step
       bf16x8 res_cur[2] = {}, res_nxt[2] = {};
       auto load_res = [&](int i, bf16x8 (&r)[2]) {
-        if (!ROT && a.residual) {
+        if (!ROT && !EXT && a.residual) {
 #pragma unroll
           for (int h = 0; h < 2; ++h)
             r[h] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.residual + (m0 + wm * 128 + i * 16 + orow + 8 * h) * a.ldr + n));
         }
       };
       load_res(0, res_cur);
+      // extended epilogue: per-row factor, residual, and a second tile operand with a per-row coefficient.  One register
+      // set: a round's operands are consumed (both rows finished into `outv`), THEN the next round's are requested into
+      // the same registers, THEN the round's stores go out -- loads never queue behind stores (vmcnt retires in order)
+      bf16x8 xres[2] = {}, xsub[2] = {};
+      float xrs[2] = {1.f, 1.f}, xkc[2] = {0.f, 0.f};
+      f32x4 xbr[2][2] = {};                            // the broadcast residual's 8 columns: reloaded only when the group changes
+      auto load_ext = [&](int i) {
+        if (EXT) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int64_t m = m0 + wm * 128 + i * 16 + orow + 8 * h;
+            if (a.row_scale) xrs[h] = a.row_scale[m];
+            if (a.residual) xres[h] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n));
+            if (a.sub) {
+              xsub[h] = *reinterpret_cast<const bf16x8*>(a.sub + m * a.ldsub + n);
+              xkc[h] = a.sub_coef[m];
+            }
+            if (a.bres) {
+              const float* bp = a.bres + (m / a.bres_rows) * a.N + n;
+              xbr[h][0] = *reinterpret_cast<const f32x4*>(bp);
+              xbr[h][1] = *reinterpret_cast<const f32x4*>(bp + 4);
+            }
+          }
+        }
+      };
+      load_ext(0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int u = i & 1;                           // alternate between the two free slots
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           asm volatile("ds_write_b128 %0, %1" ::"v"(pw[u] + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
-        if (!ROT) {
+        if (EXT && !ROT) {
+          bf16x8 outv[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = orow + 8 * h;
+            const int64_t m = m0 + wm * 128 + i * 16 + r;
+            const unsigned base = lds_addr(patch[u]) + r * 256;
+            f32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(lo) : "v"(base + (((2 * oc) ^ r) << 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(hi) : "v"(base + (((2 * oc + 1) ^ r) << 4)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(e < 4 ? lo[e] : hi[e - 4], xrs[h], bias[e]);
+            if (a.preact) {
+              bf16x8 pz;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pz[e] = (bf16)v[e];
+              *reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n) = pz;
+            }
+            if (a.epilogue & MEANT_EPI_GELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+            }
+            if (a.residual) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)xres[h][e];
+            }
+            if (a.sub) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaf(-xkc[h], (float)xsub[h][e], v[e]);
+            }
+            if (a.bres) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaf(a.bres_scale, e < 4 ? xbr[h][0][e] : xbr[h][1][e - 4], v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) outv[h][e] = (bf16)v[e];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < 8) load_ext(i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<bf16x8*>(a.C + (m0 + wm * 128 + i * 16 + orow + 8 * h) * a.ldc + n) = outv[h];
+        } else if (!ROT) {
           f32x4 lo[2], hi[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -1056,6 +1145,11 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_RAISE_LDS(gemm_bf16_nt256_kernel, 4 * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, true>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false, true>), RING * T2_BYTES);
+  const bool ext = a.row_scale || a.sub || a.bres;
+  MEANT_REQUIRE(!a.bres || (a.bres_rows > 0 && (a.N & 7) == 0 && meant_aligned16(a.bres)), MEANT_ERR_ARG, "gemm_bf16_nt: bad broadcast residual");
+  MEANT_REQUIRE(!ext || (!a.rot_qa && !(a.epilogue & MEANT_EPI_SIGMOID)), MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: extended epilogue with rotary / sigmoid");
+  MEANT_REQUIRE(!a.sub || (a.sub_coef && (a.ldsub & 7) == 0 && meant_aligned16(a.sub)), MEANT_ERR_ARG, "gemm_bf16_nt: bad sub operand");
   // big tall problems: 256 x 256 tiles (half the operand bytes per FLOP) -- once there are enough of them to occupy at least
   // half the CUs (the temporal encoder's 1536^2 Linears make 36: four times as many 128 x 128 tiles finish in a third of the time)
   if (a.M >= 1024 && a.N % 256 == 0 && ceil_div(a.M, B2) * (a.N / B2) * 2 >= meant_num_cus()) {
@@ -1074,6 +1168,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
     };
     const bool ragged_overlap = stream_ok && meant_opt(MEANT_OPT_NT_RAGGED) != 0 && a.M % B2 != 0 && a.K >= 2 * BK && (a.ldc & 7) == 0 &&
                                 (!a.residual || (a.ldr & 7) == 0) && !overlaps(a.C, a.ldc, a.residual, a.ldr, a.M) &&
+                                !overlaps(a.C, a.ldc, a.sub, a.ldsub, a.M) &&
                                 !overlaps(a.C, a.ldc, a.A, a.lda, a.M) && (!a.preact || !overlaps(a.preact, a.ldc, a.A, a.lda, a.M));
     // nt_ragged = 0 (or aliasing operands): the streaming kernel takes the first floor(M / 256) * 256 rows, the remaining < 256 rows go
     // to the 128 x 128 kernel as a second launch (row-local epilogues only: the rotary epilogue indexes its tables by the
@@ -1088,6 +1183,10 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       tail.C = a.C + m_full * a.ldc;
       if (a.residual) tail.residual = a.residual + m_full * a.ldr;
       if (a.preact) tail.preact = a.preact + m_full * a.ldc;
+      if (a.row_scale) tail.row_scale = a.row_scale + m_full;
+      if (a.sub) { tail.sub = a.sub + m_full * a.ldsub; tail.sub_coef = a.sub_coef + m_full; }
+      MEANT_REQUIRE(!a.bres || m_full % a.bres_rows == 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: broadcast residual across the head / tail split");
+      if (a.bres) tail.bres = a.bres + (m_full / a.bres_rows) * a.N;
       meant_route_hit(ROUTE_NT_SPLIT);
       const int rc = gemm_bf16_nt_launch(head, stream);
       return rc ? rc : gemm_bf16_nt_launch(tail, stream);
@@ -1105,6 +1204,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       TileSched* sched = (dynmode != 0 && grid <= 512) ? tile_sched_for(stream) : nullptr;
       meant_route_hit(a.rot_qa ? ROUTE_NT256S_ROT : ROUTE_NT256S);
       if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+      else if (ext) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
       else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
     } else {
       meant_route_hit(ROUTE_NT256);

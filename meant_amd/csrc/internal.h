@@ -35,6 +35,13 @@ struct GemmBf16Args {
   // optional rotary epilogue of the fused QKV projection (null rot_qa = off): tables float [S, R]
   const float* rot_qa; const float* rot_qb; const float* rot_ka; const float* rot_kb;
   int rot_S, rot_D, rot_Dh, rot_R;
+  // "extended" epilogue (an RMSNorm folded into this Linear, see meant_linear_fwd_rowscale / meant_linear_bwd_dx_norm):
+  //   C = act(row_scale[m] * acc + bias) + residual - sub_coef[m] * sub[m, n] + bres_scale * bres[m / bres_rows, n]   (every part optional)
+  const float* row_scale = nullptr;          // [M]
+  const bf16* sub = nullptr; int64_t ldsub = 0;
+  const float* sub_coef = nullptr;           // [M]
+  const float* bres = nullptr;               // float [M / bres_rows, N]: one row per group of bres_rows consecutive output rows
+  int bres_rows = 1; float bres_scale = 1.f; //   (the gradient of a sequence mean, broadcast over the sequence's tokens)
 };
 int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream);
 // dW[N,K] (float, +=) = dY[M,N]^T X[M,K], reduction over the token axis M; dbias[N] += colsum(dY)

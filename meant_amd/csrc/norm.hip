@@ -216,6 +216,41 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const 
   }
 }
 
+// statistics only: rinv[row] = 1 / (||x_row|| / sqrt(d) + eps), nothing else written (the normalisation itself rides the
+// consumer GEMM's epilogue as a per-row factor: meant_linear_fwd_rowscale).  One read of x.
+template <typename T, int C>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_stats_packed_kernel(const T* __restrict__ x, float* __restrict__ rinv_out,
+                                                                             int64_t rows, int d, int R, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  const float inv_sqrt_d = rsqrtf((float)d);
+  int rsel[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) rsel[c] = (lane + 64 * c) / nchunk;
+  const int64_t ngroups = rows / R;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = grp * R;
+    const T* xr = x + row0 * d;
+    Vec8<T> v[C];
+    float ss[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = load8<T>(xr + (lane + 64 * c) * 8);       // x stays cacheable: the consumer GEMM reads it next
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      ss[c] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float f = v[c].get(i); ss[c] += f * f; }
+    }
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) s += rsel[c] == r ? ss[c] : 0.f;
+      s = wave_sum(s);
+      if (lane == 0) rinv_out[row0 + r] = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+    }
+  }
+}
+
 // Pooled form: the consumer of this norm (POOL = 1) or of its input (POOL = 2) is the sequence mean-pool (meant/meant.py:231).
 // pooled[g, :] (float) = mean over the `group_rows` rows of group g of y (POOL = 1: y itself is not written at all -- it has
 // no other reader once the stack's last Linear is evaluated on the pooled features) or of x (POOL = 2: the residual
@@ -298,7 +333,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 #pragma unroll
           for (int i = 0; i < 8; ++i) psum[c][i] += o.get(i);
         } else {
-          store8s<T>(y + row0 * d + (lane + 64 * c) * 8, o);
+          if (y) store8s<T>(y + row0 * d + (lane + 64 * c) * 8, o);     // y == NULL: statistics + means of x only
 #pragma unroll
           for (int i = 0; i < 8; ++i) psum[c][i] += v[c].get(i);
         }
@@ -323,30 +358,50 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 // BC bit 0: dy is the gradient of the POOLED features, float [groups, d]: row r receives dy_g[r / group_rows] / group_rows
 // (the backward of POOL = 1 above -- no [tokens, d] broadcast is ever materialised); bit 1: the same for dres (POOL = 2).
 // BC bit 2: x is not stored at all -- it is gelu(gelu_pre), formed on load (the forward's GELU_IN)
-template <typename T, int C, int BC>
-__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// CHAIN: the result dpre (gradient of the pre-activation gelu_pre = r_up (x_up W'^T) + b_up of a Linear whose input norm rides
+// its GEMM as a per-row factor, meant_linear_fwd_rowscale) is what three more things are made of, all in this pass:
+//   dx            <- r_up[row] * dpre : the A operand of BOTH backward GEMMs of that Linear (dW' = (r dpre)^T x_up, and
+//                    (r dpre) W' = the first term of d x_up);
+//   kcoef[row]    <- rowdot(dpre, pre - b_up) r_up^2 / ((1 - eps_up r_up) d_up): the factor of x_up in the norm's own term,
+//                    d x_up = (r dpre) W' - kcoef x_up, which the input-gradient GEMM subtracts in its epilogue;
+//   partial2[blk] <- column sums of the UNSCALED dpre (the Linear's bias gradient; the scaled tensor cannot give it).
+struct NormChain { const float* up_rinv; const float* up_bias; float* kcoef; float* partial2; float up_eps; int up_d; };
+template <typename T, int C, int BC, bool CHAIN = false>
+__global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                            const float* __restrict__ scale,
                                                                            const float* __restrict__ rinv, T* __restrict__ dx,
                                                                            float* __restrict__ partial, int64_t rows, int d, int R,
                                                                            float eps, float drop_p, uint64_t seed,
                                                                            const T* __restrict__ dres, const T* __restrict__ gelu_pre,
-                                                                           int group_rows) {
+                                                                           int group_rows, NormChain ch = NormChain{}) {
   __shared__ float red[4][C * 64 * 8];                 // per wave: the gain-gradient sums of its C * 64 chunks
+  __shared__ float gain_s[CHAIN ? C * 64 * 8 : 1];     // CHAIN: the gains live in LDS (24 registers the extra accumulators need)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float inv_group = BC ? 1.0f / (float)group_rows : 0.f;
   const int nchunk = d >> 3;
   int rsel[C], col[C];
-  f32x4 g0[C], g1[C];
+  f32x4 g0[CHAIN ? 1 : C], g1[CHAIN ? 1 : C];
   float gacc[C][8];
+  if constexpr (CHAIN) {
+    for (int j = threadIdx.x; j < d; j += NORM_THREADS) gain_s[j] = scale[j];
+    __syncthreads();
+  }
+  float bacc[CHAIN ? C : 1][8];                       // CHAIN: column sums of the unscaled result
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int k = lane + 64 * c;
     rsel[c] = k / nchunk;
     col[c] = (k - rsel[c] * nchunk) * 8;
-    g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
-    g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+    if constexpr (!CHAIN) {
+      g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
+      g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bacc[c][i] = 0.f;
+    }
   }
   const int64_t ngroups = rows / R;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
@@ -375,12 +430,17 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
       float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
       if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)(row0 + rsel[c]) * d + col[c], km);
       cd[c] = 0.f;
+      f32x4 ga0, ga1;
+      if constexpr (CHAIN) {
+        ga0 = *reinterpret_cast<const f32x4*>(gain_s + col[c]);
+        ga1 = *reinterpret_cast<const f32x4*>(gain_s + col[c] + 4);
+      } else { ga0 = g0[c]; ga1 = g1[c]; }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float dyi = ((BC & 1) ? dvg[c].get(i) * inv_group : dv[c].get(i)) * km[i];
         const float xi = (BC & 4) ? pv[c].get(i) * xv[c].get(i) : xv[c].get(i);
         gacc[c][i] += dyi * xi * rr[c];
-        const float t = (i < 4 ? g0[c][i] : g1[c][i - 4]) * dyi;
+        const float t = (i < 4 ? ga0[i] : ga1[i - 4]) * dyi;
         gd[c][i] = t;
         cd[c] += t * xi;
       }
@@ -401,9 +461,20 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
         }
       }
     }
+    float rd[CHAIN ? C : 1], ru[CHAIN ? C : 1];
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) ru[c] = ch.up_rinv[row0 + rsel[c]];
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       Vec8<T> o;
+      f32x4 ub0 = {0.f, 0.f, 0.f, 0.f}, ub1 = ub0;
+      if constexpr (CHAIN) {
+        rd[c] = 0.f;
+        ub0 = *reinterpret_cast<const f32x4*>(ch.up_bias + col[c]);
+        ub1 = *reinterpret_cast<const f32x4*>(ch.up_bias + col[c] + 4);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float xi2 = (BC & 4) ? pv[c].get(i) * xv[c].get(i) : xv[c].get(i);
@@ -414,11 +485,30 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
           const float pr = pv[c].get(i);
           val *= fmaf(pr * 0.39894228040143268f, __builtin_amdgcn_exp2f(-0.72134752044448170f * pr * pr), xv[c].get(i));
         } else if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
-        o.set(i, val);
+        if constexpr (CHAIN) {
+          bacc[c][i] += val;
+          rd[c] += val * (pv[c].get(i) - (i < 4 ? ub0[i] : ub1[i - 4]));
+          o.set(i, val * ru[c]);
+        } else o.set(i, val);
       }
-      store8s<T>(dx + off + (lane + 64 * c) * 8, o);
+      if constexpr (CHAIN) store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
+      else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
+    }
+    if constexpr (CHAIN) {
+      for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += rsel[c] == r ? rd[c] : 0.f;
+        s = wave_sum(s);
+        if (lane == 0) {
+          const float rv1 = ch.up_rinv[row0 + r];
+          const float den = (1.0f - ch.up_eps * rv1) * (float)ch.up_d;      // = ||x_up|| sqrt(d) r
+          ch.kcoef[row0 + r] = den > 0.f ? s * rv1 * rv1 / den : 0.f;
+        }
+      }
     }
   }
+  __syncthreads();
   // fixed-order combine (no atomics: the gain gradient is bit-reproducible): chunk k = lane + 64 c of wave w holds column
   // (k mod nchunk) * 8 of row k / nchunk of the wave's R-row steps
 #pragma unroll
@@ -431,6 +521,20 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_packed_kernel(const 
     for (int w = 0; w < 4; ++w)
       for (int r = 0; r < R; ++r) s += red[w][r * d + j];
     partial[(int64_t)blockIdx.x * d + j] = s;
+  }
+  if constexpr (CHAIN) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * c) * 8 + i] = bacc[c][i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < R; ++r) s += red[w][r * d + j];
+      ch.partial2[(int64_t)blockIdx.x * d + j] = s;
+    }
   }
 }
 
@@ -659,7 +763,7 @@ extern "C" int meant_rmsnorm_pooled_ok(int64_t rows, int64_t d, int64_t group_ro
 extern "C" int meant_rmsnorm_fwd_pooled(const void* x, const float* scale, void* y, float* rinv, float* pooled, int64_t rows, int64_t d,
                                         int64_t group_rows, int pool_input, int gelu_input, float eps, float drop_p, uint64_t seed,
                                         int dtype, void* stream) {
-  MEANT_REQUIRE(x && scale && rinv && pooled && (y || !pool_input), MEANT_ERR_ARG, "rmsnorm_fwd_pooled: null pointer");
+  MEANT_REQUIRE(x && scale && rinv && pooled, MEANT_ERR_ARG, "rmsnorm_fwd_pooled: null pointer");   // y == NULL with pool_input: statistics + means of x only
   MEANT_REQUIRE(!(pool_input && gelu_input), MEANT_ERR_UNSUPPORTED, "rmsnorm_fwd_pooled: gelu_input goes with pool_input == 0");
   MEANT_REQUIRE(meant_rmsnorm_pooled_ok(rows, d, group_rows), MEANT_ERR_UNSUPPORTED,
                 "rmsnorm_fwd_pooled: rows=%lld d=%lld group_rows=%lld is not a packed shape (see meant_rmsnorm_pooled_ok)", (long long)rows,
@@ -706,6 +810,56 @@ extern "C" int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const voi
 #undef LAUNCH_BWDP
   MEANT_LAUNCH_CHECK("rmsnorm_bwd_pooled");
   return colsum_launch(workspace, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
+}
+
+// ---- RMSNorm folded into the consumer Linear (meant_linear_fwd_rowscale): statistics pass and chained backward ----
+extern "C" int meant_rmsnorm_stats(const void* x, float* rinv, int64_t rows, int64_t d, float eps, int dtype, void* stream) {
+  MEANT_REQUIRE(x && rinv, MEANT_ERR_ARG, "rmsnorm_stats: null pointer");
+  MEANT_REQUIRE(meant_aligned16(x), MEANT_ERR_ARG, "rmsnorm_stats: 16-byte alignment");
+  int R, C;
+  norm_packing(rows, d, R, C);
+  MEANT_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512 && R != 0, MEANT_ERR_UNSUPPORTED,
+                "rmsnorm_stats: rows=%lld d=%lld is not a packed shape (see meant_rmsnorm_pooled_ok)", (long long)rows, (long long)d);
+  const int nb = packed_blocks(rows / R);
+#define LAUNCH_STATS(CC)                                                                                                      \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_stats_packed_kernel<T, CC>), dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+                                                (const T*)x, rinv, rows, (int)d, R, eps))
+  if (C == 1) LAUNCH_STATS(1); else if (C == 2) LAUNCH_STATS(2); else LAUNCH_STATS(3);
+#undef LAUNCH_STATS
+  MEANT_LAUNCH_CHECK("rmsnorm_stats");
+  return MEANT_OK;
+}
+
+extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv, void* dx_scaled,
+                                       float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps, float drop_p, uint64_t seed,
+                                       const void* gelu_pre, const float* up_rinv, const float* up_bias, float up_eps, int64_t up_d,
+                                       float* kcoef, float* dbias_up, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && gelu_pre && scale && rinv && dx_scaled && dscale && up_rinv && up_bias && kcoef && dbias_up && workspace, MEANT_ERR_ARG,
+                "rmsnorm_bwd_chain: null pointer");
+  MEANT_REQUIRE((x != nullptr) != (dy_pooled != 0), MEANT_ERR_UNSUPPORTED,
+                "rmsnorm_bwd_chain: either token-level dy with the stored activation x, or pooled dy with x formed from gelu_pre");
+  int R, C;
+  norm_packing(rows, d, R, C);
+  MEANT_REQUIRE(rows > 0 && rows < 2147483647LL && R != 0 && (!dy_pooled || (group_rows > 0 && rows % group_rows == 0 && group_rows % R == 0)),
+                MEANT_ERR_UNSUPPORTED, "rmsnorm_bwd_chain: not a packed shape");
+  MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_chain: workspace too small");
+  const int nbp = packed_blocks_bwd(rows / R);
+  float* part1 = (float*)workspace;
+  float* part2 = part1 + (size_t)nbp * d;
+  MEANT_REQUIRE(up_d > 0 && up_d < (1LL << 30), MEANT_ERR_ARG, "rmsnorm_bwd_chain: bad up_d");
+  const NormChain ch{up_rinv, up_bias, kcoef, part2, up_eps, (int)up_d};
+#define LAUNCH_CH(CC, BB)                                                                                                     \
+    DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, BB, true>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
+                                                (const T*)dy, (const T*)x, scale, rinv, (T*)dx_scaled, part1, rows, (int)d, R, eps, drop_p, seed,  \
+                                                (const T*)nullptr, (const T*)gelu_pre, (int)(dy_pooled ? group_rows : 1), ch))
+#define LAUNCH_CH_C(BB) { if (C == 1) LAUNCH_CH(1, BB); else if (C == 2) LAUNCH_CH(2, BB); else LAUNCH_CH(3, BB); }
+  if (dy_pooled) LAUNCH_CH_C(5) else LAUNCH_CH_C(0)
+#undef LAUNCH_CH_C
+#undef LAUNCH_CH
+  MEANT_LAUNCH_CHECK("rmsnorm_bwd_chain");
+  int rc = colsum_launch(part1, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  return colsum_launch(part2, d, dbias_up, nbp, d, MEANT_F32, 1, (hipStream_t)stream);      // += : a gradient sink may be handed in
 }
 
 extern "C" int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,

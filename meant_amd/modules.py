@@ -272,11 +272,17 @@ class visionEncoder(nn.Module):
             h = e[2](e[1](n))
         h = e[3](h)
         x1 = e[4](h, residual=res)
+        fold = ops.norm_linear_ok(x1, e2[1].weight)                   # encode2[0] rides encode2[1]'s GEMM as a per-row factor
         if pool and ops.pooled_norm_ok(x1, x1.shape[1]):             # the two norms beside the mean-pool emit the means themselves
+            if fold:
+                return ops.norm_linear_gelu_norm_pooled(x1, e2[0].scale, e2[0].eps, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
             n, xm = ops.rmsnorm_fork_pooled(x1, e2[0].scale, e2[0].eps)
             return ops.linear_gelu_rmsnorm_pooled(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps), xm
-        n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
-        h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
+        if fold:
+            h, res = ops.norm_linear_gelu_norm(x1, e2[0].scale, e2[0].eps, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
+        else:
+            n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
+            h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
         if pool:
             return h, res
         return e2[4](h, residual=res)
@@ -306,11 +312,18 @@ class languageEncoder(nn.Module):
             h = e[2](e[1](n), attention_mask)
         h = e[3](h, drop_p=p1, seed=_seed() if p1 > 0 else 0)
         x1 = e[5](h, residual=res)
+        fold = ops.norm_linear_ok(x1, e2[1].weight)                   # encode2[0] rides encode2[1]'s GEMM as a per-row factor
+        seed2 = _seed() if p2 > 0 else 0
         if pool and ops.pooled_norm_ok(x1, x1.shape[1]):             # the two norms beside the mean-pool emit the means themselves
+            if fold:
+                return ops.norm_linear_gelu_norm_pooled(x1, e2[0].scale, e2[0].eps, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, seed2)
             n, xm = ops.rmsnorm_fork_pooled(x1, e2[0].scale, e2[0].eps)
-            return ops.linear_gelu_rmsnorm_pooled(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, _seed() if p2 > 0 else 0), xm
-        n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
-        h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, _seed() if p2 > 0 else 0)
+            return ops.linear_gelu_rmsnorm_pooled(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, seed2), xm
+        if fold:
+            h, res = ops.norm_linear_gelu_norm(x1, e2[0].scale, e2[0].eps, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, seed2)
+        else:
+            n, res = ops.rmsnorm_fork(x1, e2[0].scale, e2[0].eps)
+            h = ops.linear_gelu_rmsnorm(n, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps, p2, seed2)
         if pool:
             return h, res
         return e2[5](h, residual=res)

@@ -364,6 +364,180 @@ def linear_gelu_rmsnorm_pooled(x, weight, bias, scale, eps=1e-8, drop_p=0.0, see
     return _GeluRMSNormPooled.apply(pre, scale, float(eps), float(drop_p), int(seed))
 
 
+# ---- RMSNorm folded into the Linear that consumes it (bf16 tier) ---------------------------------------------------------
+# Linear(RMSNorm(x)) = r (x) (x W'^T) + b with W' = W diag(g), r = 1 / (rms(x) + eps) (utils/rms_norm.py:40-57 followed by the
+# nn.Linear of meant/meant.py:62 / :104): the normalisation is a per-row factor in the GEMM epilogue, so the normalised tensor
+# is never written, read or saved -- forward: one statistics pass over x instead of a read + write; backward: no pass at all,
+# the norm's own term d x = ... - kcoef x rides the input-gradient GEMM's epilogue, and the backward of the NEXT norm down the
+# layer (which produces the gradient of this Linear's output anyway) emits everything that term needs in the same pass
+# (meant_rmsnorm_bwd_chain).  FUSE_NORM_LINEAR = False (MEANT_FUSE_NORM_LINEAR=0) runs the separate kernels.
+FUSE_NORM_LINEAR = os.environ.get("MEANT_FUSE_NORM_LINEAR", "1") != "0"
+
+
+def norm_linear_ok(x, weight) -> bool:
+    """shapes the folded path covers: bf16 tier, K a multiple of 64, a packed norm width, 16-byte aligned rows"""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    return bool(FUSE_NORM_LINEAR and x.dtype == torch.bfloat16 and x.is_cuda and d % 64 == 0 and weight.shape[1] == d
+                and weight.shape[0] % 8 == 0 and rows > 0 and lib.meant_rmsnorm_pooled_ok(rows, d, rows))
+
+
+def _scaled_weight(weight, gain):
+    """W' = W diag(g) in fp32 (kept for the backward) and its bf16 copy"""
+    w_f, g_f = _c(weight.detach().float()), _c(gain.detach().float())
+    N, K = w_f.shape
+    wp = torch.empty_like(w_f)
+    check(lib.meant_colscale(_p(w_f), _p(g_f), _p(wp), N, K, _stream()), "colscale")
+    return w_f, g_f, wp, cast(wp, torch.bfloat16)
+
+
+def _norm_linear_backward(ctx, dpre_s, kcoef, x2, wp, w_f, g_f, dres2, dres_pooled, group_rows):
+    """the two backward GEMMs of the folded Linear and the weight-side chain rule: returns (dx2, dW or None, dg)"""
+    M, K = x2.shape
+    N = wp.shape[0]
+    dt = _dt(x2)
+    wpT = torch.empty((K, N), device=x2.device, dtype=x2.dtype)
+    check(lib.meant_transpose2d(_p(wp), F32, _p(wpT), dt, N, K, _stream()), "transpose2d")
+    dx = torch.empty_like(x2)
+    check(lib.meant_linear_bwd_dx_norm(_p(dpre_s), N, _p(wpT), _p(x2), K, _p(kcoef), _p(dres2), K if dres2 is not None else 0,
+                                       _p(dres_pooled), int(group_rows), _p(dx), K, M, N, K, dt, _stream()), "linear_bwd_dx_norm")
+    dwp = torch.zeros((N, K), device=x2.device, dtype=torch.float32)
+    _bwd_dw(dpre_s, x2, dwp, None)
+    dg = torch.zeros(K, device=x2.device, dtype=torch.float32)
+    sink = _sink_of(ctx.weight, "linear") if grad_sinks else None
+    if sink is not None and sink.view.shape == (N, K) and sink.view.is_contiguous():
+        check(lib.meant_colscale_bwd(_p(dwp), _p(w_f), _p(g_f), _p(sink.view), _p(dg), N, K, _stream()), "colscale_bwd")
+        sink.report(ctx.weight)
+        return dx, None, dg
+    dw = torch.zeros((N, K), device=x2.device, dtype=torch.float32)
+    check(lib.meant_colscale_bwd(_p(dwp), _p(w_f), _p(g_f), _p(dw), _p(dg), N, K, _stream()), "colscale_bwd")
+    return dx, dw, dg
+
+
+def _bias_grad_target(ctx, N, device):
+    """where the chained norm backward adds the Linear's bias gradient: the bias's gradient sink, or a fresh zero vector"""
+    if ctx.bias is None:
+        return torch.zeros(N, device=device, dtype=torch.float32), False
+    sink = _sink_of(ctx.bias, "linear") if grad_sinks else None
+    if sink is not None and sink.view.shape == (N,) and sink.view.is_contiguous():
+        return sink.view, True
+    return torch.zeros(N, device=device, dtype=torch.float32), False
+
+
+class _NormLinearGeluNorm(torch.autograd.Function):
+    """(dropout(RMSNorm_3(gelu(Linear(RMSNorm_0(x))))), x): the encode2 chain of an encoder layer up to its last Linear
+    (meant/meant.py:61-64, :103-107) with RMSNorm_0 folded into the Linear; the second output is x itself, the residual
+    operand further down (as _RMSNormFork).  Saved: x, its row statistics, the pre-activation, the activation."""
+
+    @staticmethod
+    def forward(ctx, x, gain0, eps0, weight, bias, gain3, eps3, drop_p, seed):
+        _need_gpu(x, weight, gain0, gain3)
+        shp = x.shape
+        K = shp[-1]
+        x2 = _c(x).view(-1, K)
+        M, N = x2.shape[0], weight.shape[0]
+        w_f, g_f, wp, wp_c = _scaled_weight(weight, gain0)
+        bias_f = _c(bias.detach().float()) if bias is not None else torch.zeros(N, device=x.device, dtype=torch.float32)
+        r0 = torch.empty(M, device=x.device, dtype=torch.float32)
+        check(lib.meant_rmsnorm_stats(_p(x2), _p(r0), M, K, eps0, _dt(x2), _stream()), "rmsnorm_stats")
+        a = torch.empty((M, N), device=x.device, dtype=x.dtype)
+        pre = torch.empty_like(a)
+        check(lib.meant_linear_fwd_rowscale(_p(x2), K, _p(wp_c), _p(bias_f), _p(r0), None, 0, _p(a), N, _p(pre), M, N, K, EPI_GELU,
+                                            _dt(x2), _stream()), "linear_fwd_rowscale")
+        y, sc3, rinv3 = _rmsnorm_fwd_raw(a, gain3, eps3, drop_p, seed)
+        ctx.weight, ctx.bias = weight, bias
+        _claim(weight, "linear"); _claim(bias, "linear")
+        ctx.save_for_backward(x2, r0, a, pre, sc3, rinv3, wp, w_f, g_f, bias_f)
+        ctx.args = (eps0, eps3, drop_p, seed, shp)
+        return y.view(*shp[:-1], N), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x2, r0, a, pre, sc3, rinv3, wp, w_f, g_f, bias_f = ctx.saved_tensors
+        eps0, eps3, drop_p, seed, shp = ctx.args
+        M, K = x2.shape
+        N = wp.shape[0]
+        dres2 = _c(dres).view(M, K) if dres is not None else None
+        if dy is None:
+            return dres, None, None, None, None, None, None, None, None
+        dy2 = _c(dy).view(M, N)
+        dpre_s = torch.empty_like(pre)
+        kcoef = torch.empty(M, device=x2.device, dtype=torch.float32)
+        dscale3 = torch.empty(N, device=x2.device, dtype=torch.float32)
+        db, db_sunk = _bias_grad_target(ctx, N, x2.device)
+        wsb = lib.meant_rmsnorm_bwd_ws(M, N)
+        ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8)
+        check(lib.meant_rmsnorm_bwd_chain(_p(dy2), 0, _p(a), _p(sc3), _p(rinv3), _p(dpre_s), _p(dscale3), M, N, 1, eps3, drop_p, seed, _p(pre),
+                                          _p(r0), _p(bias_f), eps0, K, _p(kcoef), _p(db), _dt(x2), _p(ws), wsb, _stream()), "rmsnorm_bwd_chain")
+        if db_sunk:
+            _sink_of(ctx.bias, "linear").report(ctx.bias)
+        dx, dw, dg0 = _norm_linear_backward(ctx, dpre_s, kcoef, x2, wp, w_f, g_f, dres2, None, 1)
+        return dx.view(shp), dg0, None, dw, (None if (db_sunk or ctx.bias is None) else db), dscale3, None, None, None
+
+
+def norm_linear_gelu_norm(x, gain0, eps0, weight, bias, gain3, eps3, drop_p=0.0, seed=0):
+    return _NormLinearGeluNorm.apply(x, gain0, float(eps0), weight, bias, gain3, float(eps3), float(drop_p), int(seed))
+
+
+class _NormLinearGeluNormPooled(torch.autograd.Function):
+    """the same chain in the LAST encoder layer of a stack, where its only consumer is the sequence mean-pool
+    (_GeluRMSNormPooled / _RMSNormForkPooled): (mean_s dropout(RMSNorm_3(gelu(Linear(RMSNorm_0(x))))), mean_s x), both float
+    [G, d].  x [G, S, d].  Neither the normalised input, nor the activation, nor the normalised activation is ever written."""
+
+    @staticmethod
+    def forward(ctx, x, gain0, eps0, weight, bias, gain3, eps3, drop_p, seed):
+        _need_gpu(x, weight, gain0, gain3)
+        x = _c(x)
+        G, S, K = x.shape
+        M, N = G * S, weight.shape[0]
+        x2 = x.view(M, K)
+        w_f, g_f, wp, wp_c = _scaled_weight(weight, gain0)
+        bias_f = _c(bias.detach().float()) if bias is not None else torch.zeros(N, device=x.device, dtype=torch.float32)
+        r0 = torch.empty(M, device=x.device, dtype=torch.float32)
+        xm = torch.empty((G, K), device=x.device, dtype=torch.float32)
+        check(lib.meant_rmsnorm_fwd_pooled(_p(x2), _p(g_f), None, _p(r0), _p(xm), M, K, S, 1, 0, eps0, 0.0, 0, _dt(x2), _stream()),
+              "rmsnorm_fwd_pooled")                                   # y == NULL: statistics and the means of x
+        pre = torch.empty((M, N), device=x.device, dtype=x.dtype)
+        check(lib.meant_linear_fwd_rowscale(_p(x2), K, _p(wp_c), _p(bias_f), _p(r0), None, 0, _p(pre), N, None, M, N, K, EPI_NONE,
+                                            _dt(x2), _stream()), "linear_fwd_rowscale")
+        rinv3 = torch.empty(M, device=x.device, dtype=torch.float32)
+        hm = torch.empty((G, N), device=x.device, dtype=torch.float32)
+        sc3 = _c(gain3.detach().float())
+        check(lib.meant_rmsnorm_fwd_pooled(_p(pre), _p(sc3), None, _p(rinv3), _p(hm), M, N, S, 0, 1, eps3, drop_p, seed, _dt(pre), _stream()),
+              "rmsnorm_fwd_pooled")
+        ctx.weight, ctx.bias = weight, bias
+        _claim(weight, "linear"); _claim(bias, "linear")
+        ctx.save_for_backward(x2, r0, pre, sc3, rinv3, wp, w_f, g_f, bias_f)
+        ctx.args = (eps0, eps3, drop_p, seed, (G, S, K))
+        return hm, xm
+
+    @staticmethod
+    def backward(ctx, dhm, dxm):
+        x2, r0, pre, sc3, rinv3, wp, w_f, g_f, bias_f = ctx.saved_tensors
+        eps0, eps3, drop_p, seed, (G, S, K) = ctx.args
+        M, N = G * S, wp.shape[0]
+        if dhm is None:
+            raise RuntimeError("meant_amd: the pooled encoder tail received no gradient for its pooled activations")
+        dh = _c(dhm.float())
+        dpre_s = torch.empty_like(pre)
+        kcoef = torch.empty(M, device=x2.device, dtype=torch.float32)
+        dscale3 = torch.empty(N, device=x2.device, dtype=torch.float32)
+        db, db_sunk = _bias_grad_target(ctx, N, x2.device)
+        wsb = lib.meant_rmsnorm_bwd_ws(M, N)
+        ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8)
+        check(lib.meant_rmsnorm_bwd_chain(_p(dh), 1, None, _p(sc3), _p(rinv3), _p(dpre_s), _p(dscale3), M, N, S, eps3, drop_p, seed, _p(pre),
+                                          _p(r0), _p(bias_f), eps0, K, _p(kcoef), _p(db), _dt(x2), _p(ws), wsb, _stream()), "rmsnorm_bwd_chain")
+        if db_sunk:
+            _sink_of(ctx.bias, "linear").report(ctx.bias)
+        dxm_f = _c(dxm.float()) if dxm is not None else None
+        dx, dw, dg0 = _norm_linear_backward(ctx, dpre_s, kcoef, x2, wp, w_f, g_f, None, dxm_f, S)
+        return dx.view(G, S, K), dg0, None, dw, (None if (db_sunk or ctx.bias is None) else db), dscale3, None, None, None
+
+
+def norm_linear_gelu_norm_pooled(x, gain0, eps0, weight, bias, gain3, eps3, drop_p=0.0, seed=0):
+    return _NormLinearGeluNormPooled.apply(x, gain0, float(eps0), weight, bias, gain3, float(eps3), float(drop_p), int(seed))
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):

@@ -57,7 +57,7 @@ def test_pooled_gelu_dropout_norm_against_torch_with_the_extracted_mask(dev, dty
         return gain * t / (t.norm(dim=-1, keepdim=True) / d ** 0.5 + eps)
 
     # fp32 reference on the values the device path sees (inputs rounded to the tier's storage type)
-    xr = x.to(dtype).float().requires_grad_()
+    xr = x.to(dtype).float().clone().requires_grad_()
     Wr, br, gr, g2r = (t.clone().requires_grad_() for t in (W.to(dtype).float() if dtype == torch.bfloat16 else W, b, g, g2))
     n_ref = rms(xr, g2r)                                   # rmsnorm_fork_pooled: (RMSNorm(x), mean_s x)
     xm_ref = xr.mean(dim=1)
@@ -65,7 +65,7 @@ def test_pooled_gelu_dropout_norm_against_torch_with_the_extracted_mask(dev, dty
     hm_ref = (rms(torch.nn.functional.gelu(pre), gr) * mask).mean(dim=1)
     ((hm_ref * wm).sum() + (xm_ref * wx).sum()).backward()
 
-    xd = x.to(dev).to(dtype).requires_grad_()
+    xd = x.detach().clone().to(dev).to(dtype).requires_grad_()
     Wd, bd, gd, g2d = (t.clone().to(dev).requires_grad_() for t in (W, b, g, g2))
     n, xm = ops.rmsnorm_fork_pooled(xd, g2d, eps)
     hm = ops.linear_gelu_rmsnorm_pooled(n, Wd, bd, gd, eps, p, seed)
