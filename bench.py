@@ -318,6 +318,9 @@ def main():
     ap.add_argument("--checkpoint", action="store_true", help="model.activation_checkpointing = True: every encoder layer is recomputed in backward")
     ap.add_argument("--checkpoint-layers", type=int, default=0,
                     help="recompute only the first N layers of each stack (--encoders 12 at 128 samples per GPU fits the 288 GB with N = 4)")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="run the per-GPU batch as this many micro-batches per step (gradient accumulation in the reducer's buckets, one "
+                         "collective per step): --encoders 12 keeps 128 samples per GPU per step with 64 in flight and no recomputation")
     ap.add_argument("--from-host", choices=["f64", "f32", "u8"], default=None,
                     help="also time the step fed by meant_amd.data.DeviceBatchLoader from host arrays of this pixel type "
                          "(PCIe-inclusive secondary figure, never `value`)")
@@ -373,11 +376,28 @@ def main():
     inputs, target = make_batch(B, rank, dev)
     step_events = []
 
+    micro = max(1, args.micro_batches)
+    assert B % micro == 0, "--micro-batches must divide the per-GPU batch"
+    mb = B // micro
+    chunks = [(tuple(t[i * mb:(i + 1) * mb] for t in inputs), target[i * mb:(i + 1) * mb]) for i in range(micro)]
+
     def step():
         reducer.prepare()
-        out = model(*inputs)
-        loss = cross_entropy_on_probs(out, target)          # CE on the probabilities, as in_loop_train.py:232
-        loss.backward()
+        if micro == 1:
+            out = model(*inputs)
+            loss = cross_entropy_on_probs(out, target)          # CE on the probabilities, as in_loop_train.py:232
+            loss.backward()
+        else:
+            # gradient accumulation: every micro-batch adds its share of the batch-mean loss's gradient into the reducer's
+            # buckets; only the last backward counts parameters and starts the bucket all-reduces (reducer.no_sync)
+            for i, (inp, tgt) in enumerate(chunks):
+                if i < micro - 1:
+                    with reducer.no_sync():
+                        loss = cross_entropy_on_probs(model(*inp), tgt) * (1.0 / micro)
+                        loss.backward()
+                else:
+                    loss = cross_entropy_on_probs(model(*inp), tgt) * (1.0 / micro)
+                    loss.backward()
         reducer.wait()
         if step_events is not None and timer.enabled and not iso:
             ev = torch.cuda.Event(enable_timing=True)
@@ -538,7 +558,7 @@ def main():
                "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": workload,
-                          "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "micro_batches": micro,
                           "train_mode_dropout": not args.eval_mode, "activation_checkpointing": True if args.checkpoint else (int(args.checkpoint_layers) or False), "grad_allreduce": reducer.active,
                           "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1),
                           "gflop_per_sample_executed": round(flops_per_sample_executed(E) / 1e9, 1)},

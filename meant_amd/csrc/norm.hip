@@ -415,13 +415,25 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
       const int64_t o = off + (lane + 64 * c) * 8;
       if (gelu_pre) pv[c] = load8s<T>(gelu_pre + o);
       if (BC & 4) {                                   // x = pre * Phi(pre) is not stored: keep Phi (x and gelu' are both one multiply-add away)
+        if constexpr (!CHAIN) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
+          for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
+        }
       } else xv[c] = load8s<T>(x + o);
       if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
       else dv[c] = load8s<T>(dy + o);
       if (BC & 2) rvg[c] = load8<float>(reinterpret_cast<const float*>(dres) + pg * d + col[c]);
       else if (dres) rv[c] = load8s<T>(dres + o);
+    }
+    // CHAIN: three more accumulator sets than the plain kernel have to fit the 256 registers of two waves per SIMD, so the
+    // chunks are worked on ONE AFTER THE OTHER (scheduling fences): the fp32 temporaries of one chunk at a time
+    if constexpr (CHAIN && (BC & 4) != 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     float rr[C], cd[C], gd[C][8];
 #pragma unroll
@@ -444,6 +456,7 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
         gd[c][i] = t;
         cd[c] += t * xi;
       }
+      if constexpr (CHAIN) __builtin_amdgcn_sched_barrier(0);
     }
     float kk[C];
 #pragma unroll
@@ -491,8 +504,10 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
           o.set(i, val * ru[c]);
         } else o.set(i, val);
       }
-      if constexpr (CHAIN) store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
-      else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
+      if constexpr (CHAIN) {
+        store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
+        __builtin_amdgcn_sched_barrier(0);
+      } else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
     }
     if constexpr (CHAIN) {
       for (int r = 0; r < R; ++r) {

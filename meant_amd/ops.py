@@ -631,8 +631,9 @@ def _lib_option(name: str) -> int:
 
 
 def _claim(param, site: str):
-    """forward side of the sink protocol: remember that an op of kind `site` reads `param` in this step"""
-    if grad_sinks and param is not None and torch.is_grad_enabled():
+    """forward side of the sink protocol: remember that an op of kind `site` reads `param` in this step.  (Called from inside
+    autograd.Function.forward, where grad mode is off: what matters is whether the parameter wants a gradient.)"""
+    if grad_sinks and param is not None and param.requires_grad:
         ent = grad_sinks.get(id(param))
         if ent is not None and ent.param() is param:
             ent.sites.add(site)

@@ -136,19 +136,44 @@ class TrainStep:
     """forward -> CE on probabilities -> backward (+ overlapped gradient all-reduce) -> clip + AdamW."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 5e-5, weight_decay: float = 1e-2, max_grad_norm: float = 1.0,
-                 bucket_mb: float = 64.0, direct_grads: bool = True):
-        """direct_grads (GradReducer): parameter gradients are accumulated straight into the flat buckets by the backward
+                 bucket_mb: float = 64.0, direct_grads: bool = True, micro_batches: int = 1):
+        """micro_batches: run a step's batch as this many equal slices, one forward/backward each, gradients accumulated in the
+        reducer's buckets (reducer.no_sync) -- the same gradients with 1/micro_batches of the activations in flight (the
+        reference's CLI default of 12 encoder layers at 128 samples per GPU).
+        direct_grads (GradReducer): parameter gradients are accumulated straight into the flat buckets by the backward
         kernels; pass False if the model's parameters are also differentiated outside this step (torch.autograd.grad,
         several backward passes per optimizer step without reducer.no_sync())"""
         self.model = model
         self.reducer = GradReducer(model.parameters(), bucket_mb=bucket_mb, direct_grads=direct_grads)
         self.opt = FusedAdamW(self.reducer, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.micro_batches = max(1, int(micro_batches))
 
     def __call__(self, *inputs, target):
         self.reducer.prepare()
-        out = self.model(*inputs)
-        loss = cross_entropy_on_probs(out, target)
-        loss.backward()
+        k = self.micro_batches
+        if k == 1:
+            out = self.model(*inputs)
+            loss = cross_entropy_on_probs(out, target)
+            loss.backward()
+        else:
+            B = target.shape[0]
+            assert B % k == 0, "micro_batches must divide the batch"
+            mb, outs, loss = B // k, [], 0.0
+            for i in range(k):
+                sl = slice(i * mb, (i + 1) * mb)
+                part = tuple(t[sl] if torch.is_tensor(t) else t for t in inputs)
+                if i < k - 1:
+                    with self.reducer.no_sync():
+                        o = self.model(*part)
+                        li = cross_entropy_on_probs(o, target[sl]) * (1.0 / k)
+                        li.backward()
+                else:
+                    o = self.model(*part)
+                    li = cross_entropy_on_probs(o, target[sl]) * (1.0 / k)
+                    li.backward()
+                outs.append(o.detach())
+                loss = loss + li.detach()
+            out = torch.cat(outs)
         self.reducer.wait()
         self.opt.step()
         return loss.detach(), out.detach()

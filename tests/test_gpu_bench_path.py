@@ -74,7 +74,7 @@ def test_pooled_gelu_dropout_norm_against_torch_with_the_extracted_mask(dev, dty
 
     tol = TOL[dtype]
     assert (xm.cpu() - xm_ref.detach()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-3)
-    assert (hm.cpu() - hm_ref.detach()).abs().max().item() <= tol["out"]
+    assert (hm.cpu() - hm_ref.detach()).abs().max().item() <= tol["out"] * max(1.0, hm_ref.abs().max().item())
     for name, a, r in (("x", xd, xr), ("W", Wd, Wr), ("b", bd, br), ("gain", gd, gr), ("gain_fork", g2d, g2r)):
         scale = r.grad.abs().max().item()
         err = (a.grad.float().cpu() - r.grad).abs().max().item() / scale
@@ -143,8 +143,8 @@ def bench_case(dev):
     sys.path.insert(0, ROOT)
     import bench
     model = bench.build_model(1, dev)
-    batch = bench.make_batch(128, 0, dev)
-    return model, batch
+    (tweets, images, mask), target = bench.make_batch(128, 0, dev)
+    return model, (tweets, images, mask, target)
 
 
 def test_128_sample_forward_rows_equal_two_sample_runs(dev, bench_case):

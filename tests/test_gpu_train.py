@@ -403,8 +403,37 @@ def test_grad_reducer_no_sync_accumulates_and_second_reducer_closes_the_first(de
     red2.prepare()
     ops.linear(xs[0], lin.weight, lin.bias).float().sum().backward()
     red2.wait()
-    assert lin.weight.grad.data_ptr() == red2.buckets[0].flat.data_ptr() + red2.buckets[0].offsets[red2.buckets[0].params.index(lin.weight)] * 4
+    widx = [i for i, q in enumerate(red2.buckets[0].params) if q is lin.weight][0]
+    assert lin.weight.grad.data_ptr() == red2.buckets[0].flat.data_ptr() + red2.buckets[0].offsets[widx] * 4
     del red2
     import gc
     gc.collect()
     assert id(lin.weight) not in ops.grad_sinks                            # the table does not keep a dead reducer's entries
+
+
+def test_train_step_micro_batches_give_the_same_update(dev):
+    """TrainStep(micro_batches=2): two half-batch forward/backward passes accumulated in the reducer's buckets (no_sync) move the
+    parameters exactly as one pass over the whole batch does (eval mode: no dropout masks to differ)"""
+    import meant_amd
+    from meant_amd.train import TrainStep
+    rs = np.random.RandomState(23)
+    ids = torch.from_numpy(rs.randint(0, 100, (4, 3, 16))).to(dev)
+    img = torch.from_numpy(rs.standard_normal((4, 3, 4, 32, 32)).astype("float32")).to(dev)
+    mask = torch.ones(4, 3, 16, device=dev)
+    tgt = torch.tensor([0, 1, 1, 0], device=dev)
+    after = []
+    for k in (1, 2):
+        torch.manual_seed(6)
+        model = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=2).to(dev).eval()
+        model.compute_dtype = torch.bfloat16
+        ts = TrainStep(model, lr=1e-2, max_grad_norm=None, micro_batches=k)
+        loss, out = ts(ids, img, mask, target=tgt)
+        assert out.shape == (4, 2) and torch.isfinite(loss)
+        torch.cuda.synchronize()
+        after.append(({n: p.detach().clone() for n, p in model.named_parameters()}, loss.item(),
+                      {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+        ts.reducer.close()
+    assert abs(after[0][1] - after[1][1]) < 2e-3
+    big = max(g.norm().item() for g in after[0][2].values())
+    for n, g in after[0][2].items():                       # the accumulated gradients themselves
+        assert (g - after[1][2][n]).norm().item() <= 2e-2 * max(g.norm().item(), 2e-2 * big), n
