@@ -364,8 +364,9 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 //                    (r dpre) W' = the first term of d x_up);
 //   kcoef[row]    <- rowdot(dpre, pre - b_up) r_up^2 / ((1 - eps_up r_up) d_up): the factor of x_up in the norm's own term,
 //                    d x_up = (r dpre) W' - kcoef x_up, which the input-gradient GEMM subtracts in its epilogue;
-//   partial2[blk] <- column sums of the UNSCALED dpre (the Linear's bias gradient; the scaled tensor cannot give it).
-struct NormChain { const float* up_rinv; const float* up_bias; float* kcoef; float* partial2; float up_eps; int up_d; };
+//   wrow[row]     <- 1 / r_up[row]: the Linear's bias gradient is the column sum of the UNSCALED dpre; the weight-gradient GEMM
+//                    forms it from the scaled tensor with these row weights (meant_linear_bwd_dw_rowweight).
+struct NormChain { const float* up_rinv; const float* up_bias; float* kcoef; float* wrow; float up_eps; int up_d; };
 template <typename T, int C, int BC, bool CHAIN = false>
 __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                            const float* __restrict__ scale,
@@ -375,33 +376,21 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
                                                                            const T* __restrict__ dres, const T* __restrict__ gelu_pre,
                                                                            int group_rows, NormChain ch = NormChain{}) {
   __shared__ float red[4][C * 64 * 8];                 // per wave: the gain-gradient sums of its C * 64 chunks
-  __shared__ float gain_s[CHAIN ? C * 64 * 8 : 1];     // CHAIN: the gains live in LDS (24 registers the extra accumulators need)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float inv_group = BC ? 1.0f / (float)group_rows : 0.f;
   const int nchunk = d >> 3;
   int rsel[C], col[C];
-  f32x4 g0[CHAIN ? 1 : C], g1[CHAIN ? 1 : C];
+  f32x4 g0[C], g1[C];
   float gacc[C][8];
-  if constexpr (CHAIN) {
-    for (int j = threadIdx.x; j < d; j += NORM_THREADS) gain_s[j] = scale[j];
-    __syncthreads();
-  }
-  float bacc[CHAIN ? C : 1][8];                       // CHAIN: column sums of the unscaled result
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int k = lane + 64 * c;
     rsel[c] = k / nchunk;
     col[c] = (k - rsel[c] * nchunk) * 8;
-    if constexpr (!CHAIN) {
-      g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
-      g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
-    }
+    g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
+    g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
 #pragma unroll
     for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
-    if constexpr (CHAIN) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bacc[c][i] = 0.f;
-    }
   }
   const int64_t ngroups = rows / R;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
@@ -415,25 +404,13 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
       const int64_t o = off + (lane + 64 * c) * 8;
       if (gelu_pre) pv[c] = load8s<T>(gelu_pre + o);
       if (BC & 4) {                                   // x = pre * Phi(pre) is not stored: keep Phi (x and gelu' are both one multiply-add away)
-        if constexpr (!CHAIN) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
-        }
+        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
       } else xv[c] = load8s<T>(x + o);
       if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
       else dv[c] = load8s<T>(dy + o);
       if (BC & 2) rvg[c] = load8<float>(reinterpret_cast<const float*>(dres) + pg * d + col[c]);
       else if (dres) rv[c] = load8s<T>(dres + o);
-    }
-    // CHAIN: three more accumulator sets than the plain kernel have to fit the 256 registers of two waves per SIMD, so the
-    // chunks are worked on ONE AFTER THE OTHER (scheduling fences): the fp32 temporaries of one chunk at a time
-    if constexpr (CHAIN && (BC & 4) != 0) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
     float rr[C], cd[C], gd[C][8];
 #pragma unroll
@@ -442,11 +419,7 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
       float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
       if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)(row0 + rsel[c]) * d + col[c], km);
       cd[c] = 0.f;
-      f32x4 ga0, ga1;
-      if constexpr (CHAIN) {
-        ga0 = *reinterpret_cast<const f32x4*>(gain_s + col[c]);
-        ga1 = *reinterpret_cast<const f32x4*>(gain_s + col[c] + 4);
-      } else { ga0 = g0[c]; ga1 = g1[c]; }
+      const f32x4 ga0 = g0[c], ga1 = g1[c];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float dyi = ((BC & 1) ? dvg[c].get(i) * inv_group : dv[c].get(i)) * km[i];
@@ -456,7 +429,6 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
         gd[c][i] = t;
         cd[c] += t * xi;
       }
-      if constexpr (CHAIN) __builtin_amdgcn_sched_barrier(0);
     }
     float kk[C];
 #pragma unroll
@@ -499,15 +471,12 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
           val *= fmaf(pr * 0.39894228040143268f, __builtin_amdgcn_exp2f(-0.72134752044448170f * pr * pr), xv[c].get(i));
         } else if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
         if constexpr (CHAIN) {
-          bacc[c][i] += val;
           rd[c] += val * (pv[c].get(i) - (i < 4 ? ub0[i] : ub1[i - 4]));
           o.set(i, val * ru[c]);
         } else o.set(i, val);
       }
-      if constexpr (CHAIN) {
-        store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
-        __builtin_amdgcn_sched_barrier(0);
-      } else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
+      if constexpr (CHAIN) store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
+      else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
     }
     if constexpr (CHAIN) {
       for (int r = 0; r < R; ++r) {
@@ -519,6 +488,7 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
           const float rv1 = ch.up_rinv[row0 + r];
           const float den = (1.0f - ch.up_eps * rv1) * (float)ch.up_d;      // = ||x_up|| sqrt(d) r
           ch.kcoef[row0 + r] = den > 0.f ? s * rv1 * rv1 / den : 0.f;
+          ch.wrow[row0 + r] = 1.0f / rv1;
         }
       }
     }
@@ -536,20 +506,6 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
     for (int w = 0; w < 4; ++w)
       for (int r = 0; r < R; ++r) s += red[w][r * d + j];
     partial[(int64_t)blockIdx.x * d + j] = s;
-  }
-  if constexpr (CHAIN) {
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * c) * 8 + i] = bacc[c][i];
-    __syncthreads();
-    for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
-      float s = 0.f;
-      for (int w = 0; w < 4; ++w)
-        for (int r = 0; r < R; ++r) s += red[w][r * d + j];
-      ch.partial2[(int64_t)blockIdx.x * d + j] = s;
-    }
   }
 }
 
@@ -848,8 +804,8 @@ extern "C" int meant_rmsnorm_stats(const void* x, float* rinv, int64_t rows, int
 extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv, void* dx_scaled,
                                        float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps, float drop_p, uint64_t seed,
                                        const void* gelu_pre, const float* up_rinv, const float* up_bias, float up_eps, int64_t up_d,
-                                       float* kcoef, float* dbias_up, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
-  MEANT_REQUIRE(dy && gelu_pre && scale && rinv && dx_scaled && dscale && up_rinv && up_bias && kcoef && dbias_up && workspace, MEANT_ERR_ARG,
+                                       float* kcoef, float* wrow, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && gelu_pre && scale && rinv && dx_scaled && dscale && up_rinv && up_bias && kcoef && wrow && workspace, MEANT_ERR_ARG,
                 "rmsnorm_bwd_chain: null pointer");
   MEANT_REQUIRE((x != nullptr) != (dy_pooled != 0), MEANT_ERR_UNSUPPORTED,
                 "rmsnorm_bwd_chain: either token-level dy with the stored activation x, or pooled dy with x formed from gelu_pre");
@@ -860,9 +816,8 @@ extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_chain: workspace too small");
   const int nbp = packed_blocks_bwd(rows / R);
   float* part1 = (float*)workspace;
-  float* part2 = part1 + (size_t)nbp * d;
   MEANT_REQUIRE(up_d > 0 && up_d < (1LL << 30), MEANT_ERR_ARG, "rmsnorm_bwd_chain: bad up_d");
-  const NormChain ch{up_rinv, up_bias, kcoef, part2, up_eps, (int)up_d};
+  const NormChain ch{up_rinv, up_bias, kcoef, wrow, up_eps, (int)up_d};
 #define LAUNCH_CH(CC, BB)                                                                                                     \
     DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, BB, true>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
                                                 (const T*)dy, (const T*)x, scale, rinv, (T*)dx_scaled, part1, rows, (int)d, R, eps, drop_p, seed,  \
@@ -872,9 +827,7 @@ extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void
 #undef LAUNCH_CH_C
 #undef LAUNCH_CH
   MEANT_LAUNCH_CHECK("rmsnorm_bwd_chain");
-  int rc = colsum_launch(part1, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
-  if (rc) return rc;
-  return colsum_launch(part2, d, dbias_up, nbp, d, MEANT_F32, 1, (hipStream_t)stream);      // += : a gradient sink may be handed in
+  return colsum_launch(part1, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
 }
 
 extern "C" int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
