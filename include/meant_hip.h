@@ -135,14 +135,13 @@ int meant_rmsnorm_bwd_pooled(const void* dy, int dy_pooled, const void* x, const
  *                            which is where the gradient dpre of this Linear's output comes from.  In the same pass it also
  *                            writes dx_scaled = up_rinv[m] * dpre (the operand of both backward GEMMs), kcoef[m] =
  *                            rowdot(dpre, gelu_pre - up_bias) up_rinv^2 / ((1 - up_eps up_rinv) up_d), up_d the width of the folded norm (see meant_linear_bwd_dx_norm)
- *                            and wrow[m] = 1 / up_rinv[m], the row weights with which meant_linear_bwd_dw_rowweight forms the
- *                            Linear's bias gradient (column sums of the UNSCALED dpre) from the scaled tensor.
+ *                            and dbias_up += column sums of the unscaled dpre (the Linear's bias gradient).
  *   meant_colscale / _bwd    W' = W diag(g);  dW += dW' diag(g), dg[k] += sum_n dW'[n,k] W[n,k]   (float, [N, K]). */
 int meant_rmsnorm_stats(const void* x, float* rinv, int64_t rows, int64_t d, float eps, int dtype, void* stream);
 int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv,
                             void* dx_scaled, float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps,
                             float drop_p, uint64_t seed, const void* gelu_pre, const float* up_rinv, const float* up_bias,
-                            float up_eps, int64_t up_d, float* kcoef, float* wrow, int dtype, void* workspace, size_t workspace_bytes,
+                            float up_eps, int64_t up_d, float* kcoef, float* dbias_up, int dtype, void* workspace, size_t workspace_bytes,
                             void* stream);
 int meant_colscale(const float* w, const float* g, float* out, int64_t N, int64_t K, void* stream);
 int meant_colscale_bwd(const float* dwp, const float* w, const float* g, float* dw, float* dg, int64_t N, int64_t K,
@@ -174,13 +173,10 @@ int meant_qkv_proj_fwd(const void* x, int64_t ldx, const void* w, const float* b
  * backward: dx[M,K] = dy_scaled[M,N] w  -  coef[m] x[m,:]  (+ dres) (+ dres_pooled[m / group_rows, :] / group_rows),
  *           dy_scaled / coef from meant_rmsnorm_bwd_chain; dres: the gradient through the residual branch that shares x
  *           (act dtype [M,K]); dres_pooled: float [M / group_rows, K], the gradient of the sequence means of x.
- *           dW' += dy_scaled^T x and dbias[n] += sum_m row_w[m] dy_scaled[m,n] through meant_linear_bwd_dw_rowweight. */
+ *           (dW' = dy_scaled^T x through meant_linear_bwd_dw with dbias NULL.) */
 int meant_linear_fwd_rowscale(const void* x, int64_t ldx, const void* w, const float* bias, const float* row_scale,
                               const void* residual, int64_t ldr, void* y, int64_t ldy, void* preact, int64_t M, int64_t N,
                               int64_t K, int epilogue, int dtype, void* stream);
-int meant_linear_bwd_dw_rowweight(const void* dy_scaled, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias,
-                                  const float* row_w, int64_t M, int64_t N, int64_t K, int dtype, void* workspace,
-                                  size_t workspace_bytes, void* stream);
 int meant_linear_bwd_dx_norm(const void* dy_scaled, int64_t lddy, const void* wT, const void* x, int64_t ldx,
                              const float* coef, const void* dres, int64_t lddres, const float* dres_pooled,
                              int64_t group_rows, void* dx, int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype,

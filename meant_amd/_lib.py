@@ -81,7 +81,6 @@ SIGNATURES = {
     "meant_colscale": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "meant_colscale_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
     "meant_linear_fwd_rowscale": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p]),
-    "meant_linear_bwd_dw_rowweight": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i, _p, _sz, _p]),
     "meant_linear_bwd_dx_norm": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p]),
 }
 

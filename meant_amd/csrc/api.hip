@@ -178,19 +178,6 @@ extern "C" int meant_linear_bwd_dw(const void* dy, int64_t lddy, const void* x, 
   return MEANT_ERR_ARG;
 }
 
-// weight / bias gradient of a Linear whose output gradient arrives scaled per row (meant_rmsnorm_bwd_chain): dw += dy_scaled^T x as
-// usual, dbias[n] += sum_m row_w[m] dy_scaled[m, n] -- the column sums of the UNSCALED gradient, row_w = 1 / scale.  bf16 tier.
-extern "C" int meant_linear_bwd_dw_rowweight(const void* dy_scaled, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias,
-                                             const float* row_w, int64_t M, int64_t N, int64_t K, int dtype, void* workspace,
-                                             size_t workspace_bytes, void* stream) {
-  MEANT_REQUIRE(dy_scaled && x && dw && row_w, MEANT_ERR_ARG, "linear_bwd_dw_rowweight: null pointer");
-  MEANT_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K, MEANT_ERR_ARG, "linear_bwd_dw_rowweight: bad shape");
-  MEANT_REQUIRE(dtype == MEANT_BF16 && N >= 8 && K >= 8 && !(lddy & 7) && !(ldx & 7) && meant_aligned16(dy_scaled) && meant_aligned16(x),
-                MEANT_ERR_UNSUPPORTED, "linear_bwd_dw_rowweight: bf16 tier, 16-byte aligned rows only");
-  return gemm_bf16_tn_launch((const bf16*)dy_scaled, lddy, (const bf16*)x, ldx, dw, dbias, M, N, K, workspace, workspace_bytes,
-                             (hipStream_t)stream, row_w);
-}
-
 extern "C" size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype) {
   return dtype == MEANT_F32 ? attn_f32_ws(G, S, H, Dh) : attn_bf16_ws(G, S, H, Dh);
 }

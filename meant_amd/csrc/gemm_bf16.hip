@@ -952,21 +952,17 @@ __device__ __forceinline__ void tn256_frag_issue(unsigned addr, u32x2& lo, u32x2
 // DET: instead of float atomics on dW / dbias (whose order differs from run to run) every workgroup stores its 256 x 256 partial
 // tile to `part` [split][tile][256][256] and its bias partials to `pbias` [split][tk][wk][N]; tn256_reduce_kernel then adds them
 // up in a fixed order.  Same MFMA stream, so the partial sums themselves are bit-identical between runs.
-// ROWW: row-weighted bias gradient (an instantiation of its own: the plain kernel sits at exactly 256 registers)
-template <bool DET, bool ROWW = false>
+template <bool DET>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
                                                                   int64_t ldx, float* __restrict__ dW, float* __restrict__ dbias,
                                                                   int64_t M, int64_t N, int64_t K, int ntn, int ntk,
                                                                   int64_t rows_per_split, float* __restrict__ part,
-                                                                  float* __restrict__ pbias, const float* __restrict__ row_w) {
+                                                                  float* __restrict__ pbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 2, wk = wave & 3;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = bid % (ntn * ntk);
-  // row_w: the bias gradient is sum_m row_w[m] dY[m, n] (dY arrives scaled per row: an RMSNorm folded into the Linear,
-  // meant_linear_bwd_dw_rowweight).  A step's 64 weights travel with its tiles: 256 bytes by DMA into wts[stage][64].
-  float* wts = reinterpret_cast<float*>(smem + 4 * TN2_TILE);
   const int split = bid / (ntn * ntk);
   const int tn = tile / ntk, tk = tile - tn * ntk;
   const int64_t n0 = (int64_t)tn * 256, k0 = (int64_t)tk * 256;
@@ -995,15 +991,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
 
   tn256_stage(dY, lddy, mbeg, mend, n0, smem, wave, lane);
   tn256_stage(X, ldx, mbeg, mend, k0, smem + TN2_TILE, wave, lane);
-  if (ROWW && do_bias && wave == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(row_w + mbeg + lane), (lds_ptr_t)wts, 4, 0, 0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * 2 * TN2_TILE;
     char* nxt = smem + ((t + 1) & 1) * 2 * TN2_TILE;
     // as in the NT kernel: waves 0-3 issue all DMA pieces, their SIMD partners (waves 4-7) go straight to the MFMAs
     if (t + 1 < nt && __builtin_amdgcn_readfirstlane(threadIdx.x) < 256) {
-      if (ROWW && do_bias && wave == 0)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(row_w + mbeg + (int64_t)(t + 1) * TN_BKM + lane), (lds_ptr_t)(wts + ((t + 1) & 1) * 64), 4, 0, 0);
       tn256_stage(dY, lddy, mbeg + (int64_t)(t + 1) * TN_BKM, mend, n0, nxt, wave, lane);
       tn256_stage(X, ldx, mbeg + (int64_t)(t + 1) * TN_BKM, mend, k0, nxt + TN2_TILE, wave, lane);
       tn256_stage(dY, lddy, mbeg + (int64_t)(t + 1) * TN_BKM, mend, n0, nxt, wave + 4, lane);
@@ -1029,20 +1022,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
 #pragma unroll
       for (int j = 0; j < 2; ++j) bfr[j] = pack_tr(blo[ks & 1][j], bhi[ks & 1][j]);
       if (do_bias && ks == wk && bias_step) {
-        if constexpr (ROWW) {                            // af[i][e] = dY[16 ks + 8 (lane >> 5) + e][column]: eight row weights per lane
-          f32x4 w0, w1;
-          const unsigned wa = lds_addr(wts + (t & 1) * 64 + 16 * ks + 8 * (lane >> 5));
-          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(w0), "=v"(w1) : "v"(wa) : "memory");
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) csum[i] = fmaf((float)af[i][e], e < 4 ? w0[e] : w1[e - 4], csum[i]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[i] += (float)af[i][e];
-        }
+          for (int e = 0; e < 8; ++e) csum[i] += (float)af[i][e];
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1241,7 +1224,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
 }
 
 static int tn_tail(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N, int64_t K,
-                   hipStream_t stream, const float* row_w) {
+                   hipStream_t stream) {
   // fewer than 64 trailing token rows: exact generic kernel, accumulating into the same dW / dbias
   meant_route_hit(ROUTE_TN_TAIL);
   GemmF32Args g{};
@@ -1252,7 +1235,7 @@ static int tn_tail(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, flo
   g.alpha = 1.f; g.accumulate = 1;
   int rc = gemm_f32_launch(g, stream);
   if (rc) return rc;
-  if (dbias) return colsum_launch(dY, lddy, dbias, M, N, MEANT_BF16, 1, stream, row_w);
+  if (dbias) return colsum_launch(dY, lddy, dbias, M, N, MEANT_BF16, 1, stream);
   return MEANT_OK;
 }
 
@@ -1282,7 +1265,7 @@ size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias, int64_t M, int64_t N,
-                        int64_t K, void* ws, size_t ws_bytes, hipStream_t stream, const float* row_w) {
+                        int64_t K, void* ws, size_t ws_bytes, hipStream_t stream) {
   const bool det = meant_opt(MEANT_OPT_DETERMINISTIC) != 0;
   MEANT_REQUIRE((lddy % 8) == 0 && (ldx % 8) == 0 && meant_aligned16(dY) && meant_aligned16(X), MEANT_ERR_ARG,
                 "gemm_bf16_tn: operands must be 16-byte aligned with row strides that are multiples of 8");
@@ -1290,7 +1273,7 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
   const int64_t Mtail = M % TN_BKM;
   if (Mtail) {
     const int64_t Mmain = M - Mtail;
-    int rc = tn_tail(dY + Mmain * lddy, lddy, X + Mmain * ldx, ldx, dW, dbias, Mtail, N, K, stream, row_w ? row_w + Mmain : nullptr);
+    int rc = tn_tail(dY + Mmain * lddy, lddy, X + Mmain * ldx, ldx, dW, dbias, Mtail, N, K, stream);
     if (rc || Mmain == 0) return rc;
     M = Mmain;
   }
@@ -1305,26 +1288,20 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
                     "linear_bwd_dw (deterministic): workspace of %zu bytes needed (meant_linear_bwd_dw_ws), got %zu", need, ws_bytes);
       float* part = (float*)ws;
       float* pbias = part + splits2 * N * K;
-      MEANT_RAISE_LDS((gemm_bf16_tn256_kernel<true, false>), 4 * TN2_TILE);
-      MEANT_RAISE_LDS((gemm_bf16_tn256_kernel<true, true>), 4 * TN2_TILE + 512);
+      MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<true>, 4 * TN2_TILE);
       meant_route_hit(ROUTE_TN256_DET);
-      if (row_w) hipLaunchKernelGGL((gemm_bf16_tn256_kernel<true, true>), grid, dim3(512), 4 * TN2_TILE + 512, stream, dY, lddy, X, ldx, dW, dbias, M, N, K,
-                                    (int)ntn2, (int)ntk2, rows2, part, pbias, row_w);
-      else hipLaunchKernelGGL((gemm_bf16_tn256_kernel<true, false>), grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
-                              (int)ntk2, rows2, part, pbias, row_w);
+      hipLaunchKernelGGL(gemm_bf16_tn256_kernel<true>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                         (int)ntk2, rows2, part, pbias);
       MEANT_LAUNCH_CHECK("gemm_bf16_tn256<det>");
       hipLaunchKernelGGL(tn256_reduce_kernel, dim3((unsigned)ceil_div(N * K / 4, 256)), dim3(256), 0, stream, part, dbias ? pbias : nullptr, dW, dbias,
                          N, K, (int)ntk2, (int)(ntn2 * ntk2), (int)splits2);
       MEANT_LAUNCH_CHECK("tn256_reduce");
       return MEANT_OK;
     }
-    MEANT_RAISE_LDS((gemm_bf16_tn256_kernel<false, false>), 4 * TN2_TILE);
-    MEANT_RAISE_LDS((gemm_bf16_tn256_kernel<false, true>), 4 * TN2_TILE + 512);
+    MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<false>, 4 * TN2_TILE);
     meant_route_hit(ROUTE_TN256);
-    if (row_w) hipLaunchKernelGGL((gemm_bf16_tn256_kernel<false, true>), grid, dim3(512), 4 * TN2_TILE + 512, stream, dY, lddy, X, ldx, dW, dbias, M, N, K,
-                                  (int)ntn2, (int)ntk2, rows2, (float*)nullptr, (float*)nullptr, row_w);
-    else hipLaunchKernelGGL((gemm_bf16_tn256_kernel<false, false>), grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
-                            (int)ntk2, rows2, (float*)nullptr, (float*)nullptr, row_w);
+    hipLaunchKernelGGL(gemm_bf16_tn256_kernel<false>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                       (int)ntk2, rows2, (float*)nullptr, (float*)nullptr);
     MEANT_LAUNCH_CHECK("gemm_bf16_tn256");
     return MEANT_OK;
   }
@@ -1341,6 +1318,6 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
   hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((unsigned)(ntn * ntk * splits)), dim3(256), 4 * TN_TILE_BYTES, stream, dY, lddy, X,
                      ldx, dW, M, N, K, (int)ntn, (int)ntk, rows_per);
   MEANT_LAUNCH_CHECK("gemm_bf16_tn");
-  if (dbias) return colsum_launch(dY, lddy, dbias, M, N, MEANT_BF16, 1, stream, row_w);
+  if (dbias) return colsum_launch(dY, lddy, dbias, M, N, MEANT_BF16, 1, stream);
   return MEANT_OK;
 }

@@ -104,10 +104,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
 
 // column sums of a [M, N] activation into a float accumulator: block = 64 columns x 4 row groups over
 // one strip of rows, one float atomic per column per strip (out is "+=" by contract).
-// row_w (optional): out[c] += sum_r row_w[r] x[r, c]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
-                                                      int64_t M, int64_t N, const float* __restrict__ row_w) {
+                                                      int64_t M, int64_t N) {
   __shared__ float red[4][64];
   const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
@@ -116,8 +115,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     const int64_t rows_per = (M + gridDim.y - 1) / gridDim.y;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per;
     const int64_t r1 = r0 + rows_per < M ? r0 + rows_per : M;
-    if (row_w) { for (int64_t r = r0 + rg; r < r1; r += 4) s += row_w[r] * to_f(x[r * ldx + c]); }
-    else for (int64_t r = r0 + rg; r < r1; r += 4) s += to_f(x[r * ldx + c]);
+    for (int64_t r = r0 + rg; r < r1; r += 4) s += to_f(x[r * ldx + c]);
   }
   red[rg][threadIdx.x & 63] = s;
   __syncthreads();
@@ -224,7 +222,7 @@ int gemm_f32_launch(const GemmF32Args& a, hipStream_t stream) {
   return MEANT_OK;
 }
 
-int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, int accumulate, hipStream_t stream, const float* row_w) {
+int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, int accumulate, hipStream_t stream) {
   MEANT_REQUIRE(x && out && M > 0 && N > 0, MEANT_ERR_ARG, "colsum: bad argument");
   if (!accumulate) {
     if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { meant_set_error("colsum: memset failed"); return MEANT_ERR_LAUNCH; }
@@ -232,7 +230,7 @@ int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, 
   int64_t strips = ceil_div(M, 64);
   if (strips > 512) strips = 512;
   if (meant_opt(MEANT_OPT_DETERMINISTIC)) strips = 1;   // one add per column: nothing races (slow for tall inputs; a debugging mode)
-  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)ceil_div(N, 64), (unsigned)strips), dim3(256), 0, stream, (const T*)x, ldx, out, M, N, row_w));
+  DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)ceil_div(N, 64), (unsigned)strips), dim3(256), 0, stream, (const T*)x, ldx, out, M, N));
   MEANT_LAUNCH_CHECK("colsum");
   return MEANT_OK;
 }

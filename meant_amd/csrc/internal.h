@@ -46,14 +46,12 @@ struct GemmBf16Args {
 int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream);
 // dW[N,K] (float, +=) = dY[M,N]^T X[M,K], reduction over the token axis M; dbias[N] += colsum(dY)
 // ws: partial-sum workspace of gemm_bf16_tn_ws(M, N, K) bytes, used (and required) only with the `deterministic` option
-// row_w (optional, float [M]): dbias[n] += sum_m row_w[m] dY[m, n] instead of the plain column sums (dW is not affected)
 int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx, float* dW, float* dbias,
-                        int64_t M, int64_t N, int64_t K, void* ws, size_t ws_bytes, hipStream_t stream, const float* row_w = nullptr);
+                        int64_t M, int64_t N, int64_t K, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K);
 
-// column sums: out[N] (+)= sum_m x[m, n]   (row_w given: sum_m row_w[m] x[m, n])
-int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, int accumulate, hipStream_t stream,
-                  const float* row_w = nullptr);
+// column sums: out[N] (+)= sum_m x[m, n]
+int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, int accumulate, hipStream_t stream);
 
 // attention cores
 int attn_f32_fwd(const float* qkv, float* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,

@@ -364,9 +364,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 //                    (r dpre) W' = the first term of d x_up);
 //   kcoef[row]    <- rowdot(dpre, pre - b_up) r_up^2 / ((1 - eps_up r_up) d_up): the factor of x_up in the norm's own term,
 //                    d x_up = (r dpre) W' - kcoef x_up, which the input-gradient GEMM subtracts in its epilogue;
-//   wrow[row]     <- 1 / r_up[row]: the Linear's bias gradient is the column sum of the UNSCALED dpre; the weight-gradient GEMM
-//                    forms it from the scaled tensor with these row weights (meant_linear_bwd_dw_rowweight).
-struct NormChain { const float* up_rinv; const float* up_bias; float* kcoef; float* wrow; float up_eps; int up_d; };
+//   partial2[blk] <- column sums of the UNSCALED dpre (the Linear's bias gradient; the scaled tensor cannot give it).
+struct NormChain { const float* up_rinv; const float* up_bias; float* kcoef; float* partial2; float up_eps; int up_d; };
 template <typename T, int C, int BC, bool CHAIN = false>
 __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                            const float* __restrict__ scale,
@@ -382,6 +381,9 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
   int rsel[C], col[C];
   f32x4 g0[C], g1[C];
   float gacc[C][8];
+  // CHAIN: the column sums of the unscaled result (a third set of 8 C accumulators would not fit the 256 registers of two waves
+  // per SIMD) live in LDS: slot (wave, chunk, element) of `red` belongs to one lane alone -- plain read-modify-write, no atomics
+  float* const bsum = &red[wave][lane * 8];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int k = lane + 64 * c;
@@ -391,6 +393,10 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
     g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
 #pragma unroll
     for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
+    if constexpr (CHAIN) {
+      *reinterpret_cast<f32x4*>(bsum + 512 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(bsum + 512 * c + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   const int64_t ngroups = rows / R;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
@@ -471,6 +477,7 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
           val *= fmaf(pr * 0.39894228040143268f, __builtin_amdgcn_exp2f(-0.72134752044448170f * pr * pr), xv[c].get(i));
         } else if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
         if constexpr (CHAIN) {
+          __hip_atomic_fetch_add(bsum + 512 * c + i, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_add_f32, the slot is this lane's alone
           rd[c] += val * (pv[c].get(i) - (i < 4 ? ub0[i] : ub1[i - 4]));
           o.set(i, val * ru[c]);
         } else o.set(i, val);
@@ -488,12 +495,20 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
           const float rv1 = ch.up_rinv[row0 + r];
           const float den = (1.0f - ch.up_eps * rv1) * (float)ch.up_d;      // = ||x_up|| sqrt(d) r
           ch.kcoef[row0 + r] = den > 0.f ? s * rv1 * rv1 / den : 0.f;
-          ch.wrow[row0 + r] = 1.0f / rv1;
         }
       }
     }
   }
   __syncthreads();
+  if constexpr (CHAIN) {                               // the bias sums are in `red` already, laid out like the gain sums below
+    for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < R; ++r) s += red[w][r * d + j];
+      ch.partial2[(int64_t)blockIdx.x * d + j] = s;
+    }
+    __syncthreads();
+  }
   // fixed-order combine (no atomics: the gain gradient is bit-reproducible): chunk k = lane + 64 c of wave w holds column
   // (k mod nchunk) * 8 of row k / nchunk of the wave's R-row steps
 #pragma unroll
@@ -804,8 +819,8 @@ extern "C" int meant_rmsnorm_stats(const void* x, float* rinv, int64_t rows, int
 extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void* x, const float* scale, const float* rinv, void* dx_scaled,
                                        float* dscale, int64_t rows, int64_t d, int64_t group_rows, float eps, float drop_p, uint64_t seed,
                                        const void* gelu_pre, const float* up_rinv, const float* up_bias, float up_eps, int64_t up_d,
-                                       float* kcoef, float* wrow, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
-  MEANT_REQUIRE(dy && gelu_pre && scale && rinv && dx_scaled && dscale && up_rinv && up_bias && kcoef && wrow && workspace, MEANT_ERR_ARG,
+                                       float* kcoef, float* dbias_up, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && gelu_pre && scale && rinv && dx_scaled && dscale && up_rinv && up_bias && kcoef && dbias_up && workspace, MEANT_ERR_ARG,
                 "rmsnorm_bwd_chain: null pointer");
   MEANT_REQUIRE((x != nullptr) != (dy_pooled != 0), MEANT_ERR_UNSUPPORTED,
                 "rmsnorm_bwd_chain: either token-level dy with the stored activation x, or pooled dy with x formed from gelu_pre");
@@ -816,8 +831,9 @@ extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void
   MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_bwd_chain: workspace too small");
   const int nbp = packed_blocks_bwd(rows / R);
   float* part1 = (float*)workspace;
+  float* part2 = part1 + (size_t)nbp * d;
   MEANT_REQUIRE(up_d > 0 && up_d < (1LL << 30), MEANT_ERR_ARG, "rmsnorm_bwd_chain: bad up_d");
-  const NormChain ch{up_rinv, up_bias, kcoef, wrow, up_eps, (int)up_d};
+  const NormChain ch{up_rinv, up_bias, kcoef, part2, up_eps, (int)up_d};
 #define LAUNCH_CH(CC, BB)                                                                                                     \
     DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rmsnorm_bwd_packed_kernel<T, CC, BB, true>), dim3(nbp), dim3(NORM_THREADS), 0, (hipStream_t)stream, \
                                                 (const T*)dy, (const T*)x, scale, rinv, (T*)dx_scaled, part1, rows, (int)d, R, eps, drop_p, seed,  \
@@ -827,7 +843,9 @@ extern "C" int meant_rmsnorm_bwd_chain(const void* dy, int dy_pooled, const void
 #undef LAUNCH_CH_C
 #undef LAUNCH_CH
   MEANT_LAUNCH_CHECK("rmsnorm_bwd_chain");
-  return colsum_launch(part1, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
+  int rc = colsum_launch(part1, d, dscale, nbp, d, MEANT_F32, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  return colsum_launch(part2, d, dbias_up, nbp, d, MEANT_F32, 1, (hipStream_t)stream);      // += : a gradient sink may be handed in
 }
 
 extern "C" int meant_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,

@@ -391,8 +391,8 @@ def _scaled_weight(weight, gain):
     return w_f, g_f, wp, cast(wp, torch.bfloat16)
 
 
-def _norm_linear_backward(ctx, dpre_s, kcoef, wrow, x2, wp, w_f, g_f, dres2, dres_pooled, group_rows):
-    """the two backward GEMMs of the folded Linear and the weight-side chain rule: returns (dx2, dW or None, db or None, dg)"""
+def _norm_linear_backward(ctx, dpre_s, kcoef, x2, wp, w_f, g_f, dres2, dres_pooled, group_rows):
+    """the two backward GEMMs of the folded Linear and the weight-side chain rule: returns (dx2, dW or None, dg)"""
     M, K = x2.shape
     N = wp.shape[0]
     dt = _dt(x2)
@@ -401,32 +401,27 @@ def _norm_linear_backward(ctx, dpre_s, kcoef, wrow, x2, wp, w_f, g_f, dres2, dre
     dx = torch.empty_like(x2)
     check(lib.meant_linear_bwd_dx_norm(_p(dpre_s), N, _p(wpT), _p(x2), K, _p(kcoef), _p(dres2), K if dres2 is not None else 0,
                                        _p(dres_pooled), int(group_rows), _p(dx), K, M, N, K, dt, _stream()), "linear_bwd_dx_norm")
-    # bias gradient: column sums of the UNSCALED output gradient, formed by the weight-gradient GEMM from the scaled one with
-    # the row weights 1 / r; straight into the bias's gradient sink when it has one
-    db, db_sunk, bsink = None, False, None
-    if ctx.bias is not None:
-        bsink = _sink_of(ctx.bias, "linear") if grad_sinks else None
-        if bsink is not None and bsink.view.shape == (N,) and bsink.view.is_contiguous():
-            db, db_sunk = bsink.view, True
-        else:
-            db = torch.zeros(N, device=x2.device, dtype=torch.float32)
     dwp = torch.zeros((N, K), device=x2.device, dtype=torch.float32)
-    wsb = lib.meant_linear_bwd_dw_ws(M, N, K, dt)
-    ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8) if wsb else None
-    check(lib.meant_linear_bwd_dw_rowweight(_p(dpre_s), N, _p(x2), K, _p(dwp), _p(db), _p(wrow), M, N, K, dt, _p(ws), wsb, _stream()),
-          "linear_bwd_dw_rowweight")
-    if db_sunk:
-        bsink.report(ctx.bias)
-        db = None
+    _bwd_dw(dpre_s, x2, dwp, None)
     dg = torch.zeros(K, device=x2.device, dtype=torch.float32)
     sink = _sink_of(ctx.weight, "linear") if grad_sinks else None
     if sink is not None and sink.view.shape == (N, K) and sink.view.is_contiguous():
         check(lib.meant_colscale_bwd(_p(dwp), _p(w_f), _p(g_f), _p(sink.view), _p(dg), N, K, _stream()), "colscale_bwd")
         sink.report(ctx.weight)
-        return dx, None, db, dg
+        return dx, None, dg
     dw = torch.zeros((N, K), device=x2.device, dtype=torch.float32)
     check(lib.meant_colscale_bwd(_p(dwp), _p(w_f), _p(g_f), _p(dw), _p(dg), N, K, _stream()), "colscale_bwd")
-    return dx, dw, db, dg
+    return dx, dw, dg
+
+
+def _bias_grad_target(ctx, N, device):
+    """where the chained norm backward adds the Linear's bias gradient: the bias's gradient sink, or a fresh zero vector"""
+    if ctx.bias is None:
+        return torch.zeros(N, device=device, dtype=torch.float32), False
+    sink = _sink_of(ctx.bias, "linear") if grad_sinks else None
+    if sink is not None and sink.view.shape == (N,) and sink.view.is_contiguous():
+        return sink.view, True
+    return torch.zeros(N, device=device, dtype=torch.float32), False
 
 
 class _NormLinearGeluNorm(torch.autograd.Function):
@@ -468,14 +463,16 @@ class _NormLinearGeluNorm(torch.autograd.Function):
         dy2 = _c(dy).view(M, N)
         dpre_s = torch.empty_like(pre)
         kcoef = torch.empty(M, device=x2.device, dtype=torch.float32)
-        wrow = torch.empty(M, device=x2.device, dtype=torch.float32)
         dscale3 = torch.empty(N, device=x2.device, dtype=torch.float32)
+        db, db_sunk = _bias_grad_target(ctx, N, x2.device)
         wsb = lib.meant_rmsnorm_bwd_ws(M, N)
         ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8)
         check(lib.meant_rmsnorm_bwd_chain(_p(dy2), 0, _p(a), _p(sc3), _p(rinv3), _p(dpre_s), _p(dscale3), M, N, 1, eps3, drop_p, seed, _p(pre),
-                                          _p(r0), _p(bias_f), eps0, K, _p(kcoef), _p(wrow), _dt(x2), _p(ws), wsb, _stream()), "rmsnorm_bwd_chain")
-        dx, dw, db, dg0 = _norm_linear_backward(ctx, dpre_s, kcoef, wrow, x2, wp, w_f, g_f, dres2, None, 1)
-        return dx.view(shp), dg0, None, dw, db, dscale3, None, None, None
+                                          _p(r0), _p(bias_f), eps0, K, _p(kcoef), _p(db), _dt(x2), _p(ws), wsb, _stream()), "rmsnorm_bwd_chain")
+        if db_sunk:
+            _sink_of(ctx.bias, "linear").report(ctx.bias)
+        dx, dw, dg0 = _norm_linear_backward(ctx, dpre_s, kcoef, x2, wp, w_f, g_f, dres2, None, 1)
+        return dx.view(shp), dg0, None, dw, (None if (db_sunk or ctx.bias is None) else db), dscale3, None, None, None
 
 
 def norm_linear_gelu_norm(x, gain0, eps0, weight, bias, gain3, eps3, drop_p=0.0, seed=0):
@@ -524,15 +521,17 @@ class _NormLinearGeluNormPooled(torch.autograd.Function):
         dh = _c(dhm.float())
         dpre_s = torch.empty_like(pre)
         kcoef = torch.empty(M, device=x2.device, dtype=torch.float32)
-        wrow = torch.empty(M, device=x2.device, dtype=torch.float32)
         dscale3 = torch.empty(N, device=x2.device, dtype=torch.float32)
+        db, db_sunk = _bias_grad_target(ctx, N, x2.device)
         wsb = lib.meant_rmsnorm_bwd_ws(M, N)
         ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8)
         check(lib.meant_rmsnorm_bwd_chain(_p(dh), 1, None, _p(sc3), _p(rinv3), _p(dpre_s), _p(dscale3), M, N, S, eps3, drop_p, seed, _p(pre),
-                                          _p(r0), _p(bias_f), eps0, K, _p(kcoef), _p(wrow), _dt(x2), _p(ws), wsb, _stream()), "rmsnorm_bwd_chain")
+                                          _p(r0), _p(bias_f), eps0, K, _p(kcoef), _p(db), _dt(x2), _p(ws), wsb, _stream()), "rmsnorm_bwd_chain")
+        if db_sunk:
+            _sink_of(ctx.bias, "linear").report(ctx.bias)
         dxm_f = _c(dxm.float()) if dxm is not None else None
-        dx, dw, db, dg0 = _norm_linear_backward(ctx, dpre_s, kcoef, wrow, x2, wp, w_f, g_f, None, dxm_f, S)
-        return dx.view(G, S, K), dg0, None, dw, db, dscale3, None, None, None
+        dx, dw, dg0 = _norm_linear_backward(ctx, dpre_s, kcoef, x2, wp, w_f, g_f, None, dxm_f, S)
+        return dx.view(G, S, K), dg0, None, dw, (None if (db_sunk or ctx.bias is None) else db), dscale3, None, None, None
 
 
 def norm_linear_gelu_norm_pooled(x, gain0, eps0, weight, bias, gain3, eps3, drop_p=0.0, seed=0):

@@ -179,32 +179,3 @@ def test_folded_and_separate_paths_agree_on_the_models(dev, monkeypatch):
     big = max(g.norm().item() for g in res[0][1].values())
     for k, g0 in res[0][1].items():
         assert (g0 - res[1][1][k]).norm().item() <= tol["gnorm"] * max(g0.norm().item(), 2e-2 * big), k
-
-
-@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (8192 + 40, 768, 768), (300, 128, 128), (4096, 256, 512)])
-def test_row_weighted_bias_gradient_through_the_c_abi(dev, M, N, K):
-    """meant_linear_bwd_dw_rowweight: dW += dy^T x as usual, dbias[n] += sum_m w[m] dy[m, n] (256 x 256 kernel with the weights
-    staged next to its tiles, its < 64-row tail, the 128 x 128 kernel + weighted column sums), both accumulating"""
-    from meant_amd import _lib
-    from meant_amd._lib import lib, check, BF16
-    gen = torch.Generator().manual_seed(M + K)
-    dy = torch.randn(M, N, generator=gen).to(dev).bfloat16()
-    x = torch.randn(M, K, generator=gen).to(dev).bfloat16()
-    w = (0.5 + torch.rand(M, generator=gen)).to(dev)
-    dw = torch.full((N, K), 0.25, device=dev)
-    db = torch.full((N,), -1.0, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    for det in (0, 1):
-        _lib.set_option("deterministic", det)
-        try:
-            dw.fill_(0.25); db.fill_(-1.0)
-            wsb = lib.meant_linear_bwd_dw_ws(M, N, K, BF16)
-            ws = torch.empty(max(wsb, 16), device=dev, dtype=torch.uint8)
-            check(lib.meant_linear_bwd_dw_rowweight(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), w.data_ptr(), M, N, K, BF16,
-                                                    ws.data_ptr(), wsb, st), "dw_rowweight")
-        finally:
-            _lib.set_option("deterministic", 0)
-        ref_w = 0.25 + dy.float().t() @ x.float()
-        ref_b = -1.0 + (w[:, None] * dy.float()).sum(dim=0)
-        assert (dw - ref_w).abs().max().item() <= 2e-3 * ref_w.abs().max().item(), det
-        assert (db - ref_b).abs().max().item() <= 2e-3 * ref_b.abs().max().item(), det
