@@ -375,27 +375,32 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
                                                                            const T* __restrict__ dres, const T* __restrict__ gelu_pre,
                                                                            int group_rows, NormChain ch = NormChain{}) {
   __shared__ float red[4][C * 64 * 8];                 // per wave: the gain-gradient sums of its C * 64 chunks
+  __shared__ float gain_s[CHAIN ? C * 64 * 8 : 1];     // CHAIN: the gains live in LDS (24 registers the extra accumulators need)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float inv_group = BC ? 1.0f / (float)group_rows : 0.f;
   const int nchunk = d >> 3;
   int rsel[C], col[C];
-  f32x4 g0[C], g1[C];
+  f32x4 g0[CHAIN ? 1 : C], g1[CHAIN ? 1 : C];
   float gacc[C][8];
-  // CHAIN: the column sums of the unscaled result (a third set of 8 C accumulators would not fit the 256 registers of two waves
-  // per SIMD) live in LDS: slot (wave, chunk, element) of `red` belongs to one lane alone -- plain read-modify-write, no atomics
-  float* const bsum = &red[wave][lane * 8];
+  if constexpr (CHAIN) {
+    for (int j = threadIdx.x; j < d; j += NORM_THREADS) gain_s[j] = scale[j];
+    __syncthreads();
+  }
+  float bacc[CHAIN ? C : 1][8];                       // CHAIN: column sums of the unscaled result
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int k = lane + 64 * c;
     rsel[c] = k / nchunk;
     col[c] = (k - rsel[c] * nchunk) * 8;
-    g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
-    g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+    if constexpr (!CHAIN) {
+      g0[c] = *reinterpret_cast<const f32x4*>(scale + col[c]);
+      g1[c] = *reinterpret_cast<const f32x4*>(scale + col[c] + 4);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
     if constexpr (CHAIN) {
-      *reinterpret_cast<f32x4*>(bsum + 512 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(bsum + 512 * c + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bacc[c][i] = 0.f;
     }
   }
   const int64_t ngroups = rows / R;
@@ -410,13 +415,25 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
       const int64_t o = off + (lane + 64 * c) * 8;
       if (gelu_pre) pv[c] = load8s<T>(gelu_pre + o);
       if (BC & 4) {                                   // x = pre * Phi(pre) is not stored: keep Phi (x and gelu' are both one multiply-add away)
+        if constexpr (!CHAIN) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
+          for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
+        }
       } else xv[c] = load8s<T>(x + o);
       if (BC & 1) dvg[c] = load8<float>(reinterpret_cast<const float*>(dy) + pg * d + col[c]);
       else dv[c] = load8s<T>(dy + o);
       if (BC & 2) rvg[c] = load8<float>(reinterpret_cast<const float*>(dres) + pg * d + col[c]);
       else if (dres) rv[c] = load8s<T>(dres + o);
+    }
+    // CHAIN: three more accumulator sets than the plain kernel have to fit the 256 registers of two waves per SIMD, so the
+    // chunks are worked on ONE AFTER THE OTHER (scheduling fences): the fp32 temporaries of one chunk at a time
+    if constexpr (CHAIN && (BC & 4) != 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[c].set(i, gelu_phi_fast(pv[c].get(i)));
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     float rr[C], cd[C], gd[C][8];
 #pragma unroll
@@ -425,7 +442,11 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
       float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
       if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)(row0 + rsel[c]) * d + col[c], km);
       cd[c] = 0.f;
-      const f32x4 ga0 = g0[c], ga1 = g1[c];
+      f32x4 ga0, ga1;
+      if constexpr (CHAIN) {
+        ga0 = *reinterpret_cast<const f32x4*>(gain_s + col[c]);
+        ga1 = *reinterpret_cast<const f32x4*>(gain_s + col[c] + 4);
+      } else { ga0 = g0[c]; ga1 = g1[c]; }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float dyi = ((BC & 1) ? dvg[c].get(i) * inv_group : dv[c].get(i)) * km[i];
@@ -435,6 +456,7 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
         gd[c][i] = t;
         cd[c] += t * xi;
       }
+      if constexpr (CHAIN) __builtin_amdgcn_sched_barrier(0);
     }
     float kk[C];
 #pragma unroll
@@ -477,13 +499,15 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
           val *= fmaf(pr * 0.39894228040143268f, __builtin_amdgcn_exp2f(-0.72134752044448170f * pr * pr), xv[c].get(i));
         } else if (gelu_pre) val *= gelu_grad_t<T>(pv[c].get(i));
         if constexpr (CHAIN) {
-          __hip_atomic_fetch_add(bsum + 512 * c + i, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_add_f32, the slot is this lane's alone
+          bacc[c][i] += val;
           rd[c] += val * (pv[c].get(i) - (i < 4 ? ub0[i] : ub1[i - 4]));
           o.set(i, val * ru[c]);
         } else o.set(i, val);
       }
-      if constexpr (CHAIN) store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
-      else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
+      if constexpr (CHAIN) {
+        store8<T>(dx + off + (lane + 64 * c) * 8, o);       // read twice right away (dW and dX GEMMs): keep it cacheable
+        __builtin_amdgcn_sched_barrier(0);
+      } else store8s<T>(dx + off + (lane + 64 * c) * 8, o);
     }
     if constexpr (CHAIN) {
       for (int r = 0; r < R; ++r) {
@@ -500,15 +524,6 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
     }
   }
   __syncthreads();
-  if constexpr (CHAIN) {                               // the bias sums are in `red` already, laid out like the gain sums below
-    for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
-      float s = 0.f;
-      for (int w = 0; w < 4; ++w)
-        for (int r = 0; r < R; ++r) s += red[w][r * d + j];
-      ch.partial2[(int64_t)blockIdx.x * d + j] = s;
-    }
-    __syncthreads();
-  }
   // fixed-order combine (no atomics: the gain gradient is bit-reproducible): chunk k = lane + 64 c of wave w holds column
   // (k mod nchunk) * 8 of row k / nchunk of the wave's R-row steps
 #pragma unroll
@@ -521,6 +536,20 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
     for (int w = 0; w < 4; ++w)
       for (int r = 0; r < R; ++r) s += red[w][r * d + j];
     partial[(int64_t)blockIdx.x * d + j] = s;
+  }
+  if constexpr (CHAIN) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * c) * 8 + i] = bacc[c][i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += NORM_THREADS) {
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < R; ++r) s += red[w][r * d + j];
+      ch.partial2[(int64_t)blockIdx.x * d + j] = s;
+    }
   }
 }
 

@@ -370,8 +370,14 @@ def linear_gelu_rmsnorm_pooled(x, weight, bias, scale, eps=1e-8, drop_p=0.0, see
 # is never written, read or saved -- forward: one statistics pass over x instead of a read + write; backward: no pass at all,
 # the norm's own term d x = ... - kcoef x rides the input-gradient GEMM's epilogue, and the backward of the NEXT norm down the
 # layer (which produces the gradient of this Linear's output anyway) emits everything that term needs in the same pass
-# (meant_rmsnorm_bwd_chain).  FUSE_NORM_LINEAR = False (MEANT_FUSE_NORM_LINEAR=0) runs the separate kernels.
-FUSE_NORM_LINEAR = os.environ.get("MEANT_FUSE_NORM_LINEAR", "1") != "0"
+# (meant_rmsnorm_bwd_chain).
+# OFF by default: measured on the bench step ("RMSNorm folded into the consumer Linear") the fold saves
+# 0.25 ms of forward passes and the whole RMSNorm backward of encode2[0] (0.66 ms text, 0.24 ms vision per layer), but the
+# chained norm backward that has to emit the scaled gradient, the row coefficients and the bias gradient on top of its own
+# work costs 0.63 ms more than the plain kernel (a third accumulator set per lane: 256 registers, scheduling fences) and the
+# extended GEMM epilogue 0.06 ms: the step comes out even (2963-3003 against 3013-3024 samples/s).  MEANT_FUSE_NORM_LINEAR=1
+# (or ops.FUSE_NORM_LINEAR = True) turns it on; the parity tests run both paths.
+FUSE_NORM_LINEAR = os.environ.get("MEANT_FUSE_NORM_LINEAR", "0") == "1"
 
 
 def norm_linear_ok(x, weight) -> bool:

@@ -31,7 +31,7 @@ def _mask_of(rows, d, p, seed, dev):
 
 @pytest.mark.parametrize("p", [0.0, 0.5])
 @pytest.mark.parametrize("d,G,S", [(768, 5, 64), (128, 4, 24), (256, 33, 8), (768, 2, 196)])
-def test_norm_linear_gelu_norm_against_torch(dev, d, G, S, p):
+def test_norm_linear_gelu_norm_against_torch(dev, monkeypatch, d, G, S, p):
     """ops.norm_linear_gelu_norm: (dropout(RMSNorm(gelu(Linear(RMSNorm(x))))), x) with a residual gradient, forward and every
     gradient against an fp32 evaluation with the same dropout mask; and the separate-kernel path agrees with it to the same gates"""
     from meant_amd import ops
@@ -45,6 +45,7 @@ def test_norm_linear_gelu_norm_against_torch(dev, d, G, S, p):
     wy = torch.randn(G, S, d, generator=gen)
     wr = torch.randn(G, S, d, generator=gen)
     mask = _mask_of(G * S, d, p, seed, dev).view(G, S, d)
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", True)
     assert ops.norm_linear_ok(x.to(dev).bfloat16(), W)
 
     xr = x.bfloat16().float().clone().requires_grad_()
