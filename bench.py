@@ -187,6 +187,37 @@ class GemmTimer:
             out[kind] = ent
         return out
 
+    @staticmethod
+    def pmc_ratios():
+        """measured HBM bytes (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes: profiles/r03_hbm_traffic_norm_attention.json,
+        produced by tools/pmc_step_kernels.py + tools/parse_pmc_kernels.py) over the algorithmic bytes that `others` prices each
+        kernel at, per kind and shape.  A lookup in tracked counter files, like `traffic` -- None when they are missing."""
+        path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_norm_attention.json")
+        if not os.path.exists(path):
+            return None
+        k = json.load(open(path))["kernels"]
+        def units(sub, tag, lo, hi):
+            for name, v in k.items():
+                if sub in name and f"[{tag}," in name and lo <= v["in_units_of_one_token_tensor"] <= hi:
+                    return v["in_units_of_one_token_tensor"]
+            return None
+        out = {}
+        for tag in ("text", "vision"):
+            ent = {}
+            # algorithmic figures in token tensors: norm fwd 2, bwd 3 (+1 with the residual gradient or the GELU pre-activation),
+            # attention fwd 4, bwd 9 (SURVEY 8d prices ONE pass; the two-pass scheme here reads q, k, v, dO twice: 12)
+            for kind, sub, alg, lo, hi in (("rmsnorm_fwd", "rmsnorm_fwd_packed", 2.0, 1.9, 2.2), ("rmsnorm_bwd (+dres)", "rmsnorm_bwd_packed_kernelIDF16bLi3ELi0ELb0E", 4.0, 3.9, 4.2),
+                                           ("rmsnorm_bwd", "rmsnorm_bwd_packed_kernelIDF16bLi3ELi0ELb0E", 3.0, 2.9, 3.2), ("attn_fwd", "attn_fwd_kernel", 4.0, 3.5, 6.0)):
+                u = units(sub, tag, lo, hi)
+                if u is not None:
+                    ent[kind] = round(u / alg, 3)
+            dq, dkv = units("attn_bwd_dq", tag, 5.0, 9.0), units("attn_bwd_dkv", tag, 5.0, 9.0)
+            if dq and dkv:
+                ent["attn_bwd (dq + dkv)"] = round((dq + dkv) / 9.0, 3)
+                ent["attn_bwd vs the two-pass minimum of 12"] = round((dq + dkv) / 12.0, 3)
+            out[tag] = ent
+        return {"measured_over_algorithmic_hbm_bytes": out, "source": "profiles/r03_hbm_traffic_norm_attention.json"}
+
     def summary(self, recs=None):
         tot_t, tot_f, n = 0.0, 0.0, 0
         for e0, e1, f, _ in (self.recs if recs is None else recs):
@@ -199,10 +230,10 @@ class GemmTimer:
 
     def traffic_per_launch(self):
         """HBM bytes per launch of the dominant kernel, averaged over the launches timed above, from the PMC table
-        in profiles/r02_nt256s_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+        in profiles/r03_nt256s_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
         corrections applied; measured on the plain epilogue) plus the algorithmic bytes of the extra epilogue
         operands (residual read / pre-activation write).  None if a launched shape is not in the table."""
-        path = os.path.join(ROOT, "profiles", "r02_nt256s_hbm_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r03_nt256s_hbm_traffic.json")
         if not os.path.exists(path):
             return None
         table = json.load(open(path))["shapes"]
@@ -544,6 +575,7 @@ def main():
             roofline["timed_in"] = f"{iso_steps} extra single-stream steps after the timed region"
             roofline["achieved_while_sharing_cus_with_second_stream"] = round(gf2 / gt2 / 1e12, 1) if gt2 > 0 else None
         roofline["others"] = timer.others_summary()
+        roofline["others_pmc"] = timer.pmc_ratios()
         lag_, s_, n_, ncls_, _ = _shape()
         metric = {"meant": "samples/sec fwd+bwd, MEANT lag=12 d=768", "meant_vqa": "samples/sec fwd+bwd, meant_vqa d=768 seq=512",
                   "meant_vision": "samples/sec fwd+bwd, meant_vision lag=1 d=768"}[MODEL]

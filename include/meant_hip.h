@@ -332,6 +332,11 @@ int meant_embedding_bwd(const void* dout, const int64_t* ids, float* dtable, int
  * equal id are summed on chip before one atomic row add, so repeated tokens do not contend (d <= 1024). */
 int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorted_ids, const int64_t* order, float* dtable,
                                int64_t n, int64_t d, int64_t V, int dtype, void* stream);
+/* the rows of ids in [id_lo, id_hi) only: the table's gradient produced in row slices, so that a data-parallel caller can start
+ * the all-reduce of a slice while the next one is still being summed (the 196 MB table is two thirds of the gradient bytes and
+ * final only with the last kernel of backward).  The union over a partition of [0, V) equals meant_embedding_bwd_sorted. */
+int meant_embedding_bwd_sorted_range(const void* dout, const int64_t* sorted_ids, const int64_t* order, float* dtable,
+                                     int64_t n, int64_t d, int64_t V, int64_t id_lo, int64_t id_hi, int dtype, void* stream);
 
 /* ---- train-step tail ------------------------------------------- in_loop_train.py:232-238,547-548
  * CrossEntropyLoss (mean) applied to the model's probabilities [B, C] as the reference does: loss_accum[0] +=

@@ -417,11 +417,14 @@ constexpr int EMB_SEG = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const T* __restrict__ dout, const int64_t* __restrict__ sorted_ids,
                                                                     const int64_t* __restrict__ order, float* __restrict__ dtable,
-                                                                    int64_t n, int d, int64_t V, int det) {
+                                                                    int64_t n, int d, int64_t V, int det, int64_t id_lo, int64_t id_hi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * EMB_SEG;
   if (j0 >= n) return;
   int64_t j1 = j0 + EMB_SEG < n ? j0 + EMB_SEG : n;
+  // [id_lo, id_hi): only the rows of this id range are produced (meant_embedding_bwd_sorted_range: the table's gradient in row
+  // slices, each handed to its collective as soon as it is final).  The ids are sorted: a stretch outside the range leaves at once.
+  if (sorted_ids[j1 - 1] < id_lo || sorted_ids[j0] >= id_hi) return;
   if (det) {
     // option "deterministic": no atomics.  A run belongs to the wave in whose stretch it STARTS: that wave follows it to its end
     // (however far), the others skip the part of their stretch that continues an earlier run.  Slow for a hot id; a debugging mode.
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const T* __re
   bool shared = !det && j0 > 0 && sorted_ids[j0 - 1] == cur;   // the first run started in the previous stretch
 
   auto flush = [&](int64_t id, bool atomic) {
-    if (id < 0 || id >= V) return;
+    if (id < 0 || id >= V || id < id_lo || id >= id_hi) return;
     float* row = dtable + id * d;
     if (atomic) {
 #pragma unroll
@@ -762,8 +765,23 @@ extern "C" int meant_embedding_bwd_sorted(const void* dout, const int64_t* sorte
   const int64_t nb = ceil_div(n, 4 * EMB_SEG);
   DISPATCH_DTYPE(dtype, T,
                  hipLaunchKernelGGL(embedding_bwd_sorted_kernel<T>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const T*)dout,
-                                    sorted_ids, order, dtable, n, (int)d, V, meant_opt(MEANT_OPT_DETERMINISTIC) != 0));
+                                    sorted_ids, order, dtable, n, (int)d, V, meant_opt(MEANT_OPT_DETERMINISTIC) != 0, (int64_t)0, V));
   MEANT_LAUNCH_CHECK("embedding_bwd_sorted");
+  return MEANT_OK;
+}
+
+extern "C" int meant_embedding_bwd_sorted_range(const void* dout, const int64_t* sorted_ids, const int64_t* order, float* dtable, int64_t n,
+                                                int64_t d, int64_t V, int64_t id_lo, int64_t id_hi, int dtype, void* stream) {
+  EW_REQ(dout && sorted_ids && order && dtable && n > 0 && d > 0 && V > 0 && 0 <= id_lo && id_lo <= id_hi && id_hi <= V,
+         "embedding_bwd_sorted_range: bad argument");
+  MEANT_REQUIRE(d <= 1024 && d % 8 == 0, MEANT_ERR_UNSUPPORTED, "embedding_bwd_sorted_range: d=%lld must be a multiple of 8 and <= 1024", (long long)d);
+  EW_REQ(meant_aligned16(dout) && meant_aligned16(dtable), "embedding_bwd_sorted_range: 16-byte alignment");
+  if (id_lo == id_hi) return MEANT_OK;
+  const int64_t nb = ceil_div(n, 4 * EMB_SEG);
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(embedding_bwd_sorted_kernel<T>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const T*)dout,
+                                    sorted_ids, order, dtable, n, (int)d, V, meant_opt(MEANT_OPT_DETERMINISTIC) != 0, id_lo, id_hi));
+  MEANT_LAUNCH_CHECK("embedding_bwd_sorted_range");
   return MEANT_OK;
 }
 

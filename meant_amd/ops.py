@@ -630,6 +630,17 @@ class GradSink:
         if r is not None:
             r._sink_report(p)
 
+    def row_slices(self, p) -> int:
+        """in how many row slices the reducer wants this parameter's gradient delivered (1: all at once)"""
+        r = self.reducer()
+        return r._row_slices(p) if r is not None else 1
+
+    def report_rows(self, p, row_lo: int, row_hi: int, last: bool):
+        """rows [row_lo, row_hi) of the parameter's gradient are final in the bucket view"""
+        r = self.reducer()
+        if r is not None:
+            r._sink_report_rows(p, row_lo, row_hi, last)
+
 
 def _lib_option(name: str) -> int:
     from . import _lib
@@ -1182,6 +1193,16 @@ class _Embedding(torch.autograd.Function):
         if d <= 1024 and d % 8 == 0 and (n >= 4096 or _lib_option("deterministic")):   # the other kernel is float atomics per token
             # index preparation (a sort of the token ids) is host-side plumbing; the reduction itself is the HIP kernel
             sorted_ids, order = torch.sort(ids_c.view(-1))
+            nsl = sink.row_slices(ctx.table) if sink is not None else 1
+            if nsl > 1:
+                # data parallel: the table's gradient is the last thing backward produces and two thirds of the bytes to reduce.
+                # It is summed in row slices; each slice's all-reduce starts while the next slice is being summed
+                for c in range(nsl):
+                    lo, hi = V * c // nsl, V * (c + 1) // nsl
+                    check(lib.meant_embedding_bwd_sorted_range(_p(dout), _p(sorted_ids), _p(order), _p(dtab), n, d, V, lo, hi, _dt(dout),
+                                                               _stream()), "embedding_bwd_sorted_range")
+                    sink.report_rows(ctx.table, lo, hi, c == nsl - 1)
+                return None, None, None
             check(lib.meant_embedding_bwd_sorted(_p(dout), _p(sorted_ids), _p(order), _p(dtab), n, d, V, _dt(dout), _stream()),
                   "embedding_bwd_sorted")
         else:

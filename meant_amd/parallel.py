@@ -32,16 +32,17 @@ def _padded(n: int) -> int:
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "handle", "streams")
+    __slots__ = ("flat", "params", "offsets", "pending", "handle", "streams", "slice_handles")
 
     def __init__(self, flat, params, offsets):
         self.flat, self.params, self.offsets, self.pending, self.handle = flat, params, offsets, 0, None
         self.streams = []
+        self.slice_handles = []
 
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None,
-                 average: bool = True, direct_grads: bool = False):
+                 average: bool = True, direct_grads: bool = False, row_slices: int = 4):
         """direct_grads: let the Linear / embedding backward write dW / db straight into the bucket views
         (meant_amd.ops.grad_sinks) instead of returning fresh tensors for autograd to add to them.  A parameter that two
         different kinds of op read in one step (a word embedding tied to the vocabulary decoder) is detected in forward
@@ -108,6 +109,10 @@ class GradReducer:
                 self._owner[id(p)] = b
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
         self.direct_grads = direct_grads
+        # a parameter that fills a bucket on its own and is larger than the bucket size (the 64001 x 768 embedding table) may be
+        # delivered by its backward in this many row slices, each reduced as soon as it is final (direct_grads only)
+        self.row_slices = max(1, int(row_slices))
+        self.row_slice_min_bytes = 32 * 1024 * 1024
         self._reported = set()
         self._sink_ids = []
         self.prepare()
@@ -174,6 +179,7 @@ class GradReducer:
             b.pending = len(b.params)
             b.handle = None
             b.streams = []
+            b.slice_handles = []
         for i in self._sink_ids:
             ent = ops.grad_sinks.get(i)
             if ent is not None:
@@ -199,6 +205,33 @@ class GradReducer:
                                "in one backward pass (shared weights?); construct the reducer with direct_grads=False")
         self._reported.add(id(p))
         self._count(p)
+
+    def _row_slices(self, p) -> int:
+        b = self._owner.get(id(p))
+        if b is None or not self.active or not self._sync or len(b.params) != 1 or p.dim() != 2 or p.numel() * 4 < self.row_slice_min_bytes:
+            return 1
+        return self.row_slices
+
+    def _sink_report_rows(self, p, row_lo: int, row_hi: int, last: bool):
+        """rows [row_lo, row_hi) of a parameter that owns its bucket are final: reduce that slice now"""
+        if not self._sync:
+            return
+        b = self._owner[id(p)]
+        if id(p) in self._reported:
+            raise RuntimeError("GradReducer(direct_grads=True): a parameter delivered in row slices also reported as a whole")
+        ncol = p.shape[1]
+        sl = b.flat[b.offsets[0] + row_lo * ncol:b.offsets[0] + row_hi * ncol]
+        if sl.numel():
+            if p.is_cuda:
+                ls = self._launch_stream(p.device)
+                ls.wait_stream(torch.cuda.current_stream(p.device))
+                with torch.cuda.stream(ls):
+                    b.slice_handles.append(dist.all_reduce(sl, op=self._op(), group=self.group, async_op=True))
+            else:
+                b.slice_handles.append(dist.all_reduce(sl, op=self._op(), group=self.group, async_op=True))
+        if last:
+            self._reported.add(id(p))
+            b.pending -= 1                                # the bucket is complete; its collectives are the slices'
 
     def _hook(self, p):
         """autograd's post-accumulate hook; a parameter whose gradient went through its sink has been counted already"""
@@ -242,9 +275,13 @@ class GradReducer:
         their bucket reduced here) and apply the 1/world average"""
         for b in self.buckets:
             if self.active:
-                if b.handle is None:
-                    b.handle = dist.all_reduce(b.flat, op=self._op(), group=self.group, async_op=True)
-                b.handle.wait()
+                if b.slice_handles:                       # delivered and reduced in row slices (see _sink_report_rows)
+                    for h in b.slice_handles:
+                        h.wait()
+                else:
+                    if b.handle is None:
+                        b.handle = dist.all_reduce(b.flat, op=self._op(), group=self.group, async_op=True)
+                    b.handle.wait()
                 if self.average and not self.fused_avg:
                     b.flat.mul_(1.0 / self.world)
 

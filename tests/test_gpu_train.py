@@ -437,3 +437,71 @@ def test_train_step_micro_batches_give_the_same_update(dev):
     big = max(g.norm().item() for g in after[0][2].values())
     for n, g in after[0][2].items():                       # the accumulated gradients themselves
         assert (g - after[1][2][n]).norm().item() <= 2e-2 * max(g.norm().item(), 2e-2 * big), n
+
+
+_EMB_SLICES_TWO_RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MEANT_REPO"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from meant_amd import ops
+from meant_amd.parallel import GradReducer
+V, d = 6001, 128
+torch.manual_seed(0)
+emb = torch.nn.Embedding(V, d).cuda()
+lin = torch.nn.Linear(d, d).cuda()
+g = torch.Generator().manual_seed(7)
+ids = torch.randint(0, V, (2, 8192), generator=g)[rank].cuda()
+wts = torch.randn(2, 8192, d, generator=g)[rank].cuda()
+red = GradReducer(list(emb.parameters()) + list(lin.parameters()), bucket_mb=1.0, direct_grads=True, row_slices=int(os.environ["MEANT_SLICES"]))
+red.row_slice_min_bytes = 0
+assert len(red._owner[id(emb.weight)].params) == 1
+for _ in range(2):
+    red.prepare()
+    x = ops.embedding(ids, emb.weight, torch.bfloat16)
+    (ops.linear(x, lin.weight, lin.bias).float() * wts).sum().backward()
+    nh = len(red._owner[id(emb.weight)].slice_handles)
+    red.wait()
+assert nh == (int(os.environ["MEANT_SLICES"]) if int(os.environ["MEANT_SLICES"]) > 1 else 0), nh
+torch.cuda.synchronize()
+if rank == 0:
+    torch.save({"emb": emb.weight.grad.detach().cpu().clone(), "w": lin.weight.grad.detach().cpu().clone()}, os.environ["MEANT_OUT"])
+dist.barrier()
+dist.destroy_process_group()
+print("SLICES_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("slices", [1, 4])
+def test_embedding_gradient_reduced_in_row_slices(dev, tmp_path, slices):
+    """the embedding table's gradient produced and all-reduced in row slices (meant_embedding_bwd_sorted_range + one collective per
+    slice, each started while the next slice is being summed): two ranks on one GPU over gloo; the averaged gradient equals one
+    process on both shards, for 4 slices as for the single-collective path"""
+    import os
+    import subprocess
+    import sys
+    from meant_amd import ops
+    opath = str(tmp_path / "slices.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
+                   MEANT_REPO=root, MEANT_OUT=opath, MEANT_SLICES=str(slices), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _EMB_SLICES_TWO_RANKS], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "SLICES_OK" in so, so[-2000:] + se[-4000:]
+    got = torch.load(opath)
+    V, d = 6001, 128
+    torch.manual_seed(0)
+    emb = torch.nn.Embedding(V, d).to(dev)
+    lin = torch.nn.Linear(d, d).to(dev)
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, V, (2, 8192), generator=g).to(dev)
+    wts = torch.randn(2, 8192, d, generator=g).to(dev)
+    x = ops.embedding(ids, emb.weight, torch.bfloat16)
+    ((ops.linear(x, lin.weight, lin.bias).float() * wts).sum() * 0.5).backward()        # the average over the two ranks' sums
+    for k, ref in (("emb", emb.weight.grad), ("w", lin.weight.grad)):
+        ref = ref.float().cpu()
+        assert (got[k] - ref).abs().max().item() <= 5e-3 * ref.abs().max().item(), k

@@ -10,7 +10,7 @@ SHAPES = [(786432, 2304, 768), (786432, 768, 768), (786432, 768, 2304),
           (301056, 768, 1024), (301056, 2304, 768), (301056, 768, 768), (301056, 768, 2304)]
 
 def per_dispatch(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     vals = []
     for r in csv.DictReader(open(f)):
         if "gemm_bf16_nt256s_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
