@@ -138,6 +138,29 @@ for a, b in zip(g1, g0):
     assert (a - b).abs().max().item() <= 1e-3 * max(b.abs().max().item(), 1e-6), "a one-rank average must be the identity"
 x = torch.arange(8, device="cuda", dtype=torch.float32)
 dist.all_reduce(x, op=dist.ReduceOp.AVG); assert torch.equal(x.cpu(), torch.arange(8, dtype=torch.float32))
+# the embedding table's gradient delivered and reduced in row slices, over the real RCCL call sequence (one collective per slice from
+# the launch stream, ncclAvg, joined in wait())
+from meant_amd import ops
+os.environ["MEANT_REDUCE_ALWAYS"] = "1"
+emb, lin = torch.nn.Embedding(6001, 128).cuda(), torch.nn.Linear(128, 128).cuda()
+ids = torch.randint(0, 6001, (8192,), device="cuda")
+def sliced(slices):
+    for p in list(emb.parameters()) + list(lin.parameters()):
+        p.grad = None
+    red = GradReducer(list(emb.parameters()) + list(lin.parameters()), bucket_mb=1.0, direct_grads=True, row_slices=slices)
+    red.row_slice_min_bytes = 0
+    red.prepare()
+    ops.linear(ops.embedding(ids, emb.weight, torch.bfloat16), lin.weight, lin.bias).float().sum().backward()
+    n = len(red._owner[id(emb.weight)].slice_handles)
+    red.wait()
+    torch.cuda.synchronize()
+    g = emb.weight.grad.clone()
+    red.close()
+    return g, n
+ga, na = sliced(4)
+gb, nb1 = sliced(1)
+assert na == 4 and nb1 == 0, (na, nb1)
+assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item()
 dist.destroy_process_group()
 print("RCCL_ONE_RANK_OK", nb)
 """
