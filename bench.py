@@ -236,7 +236,13 @@ class GemmTimer:
         path = os.path.join(ROOT, "profiles", "r03_nt256s_hbm_traffic.json")
         if not os.path.exists(path):
             return None
-        table = json.load(open(path))["shapes"]
+        doc = json.load(open(path))
+        table = doc["shapes"]
+        # the table was measured on one version of the kernel's source: say so when the source has moved on since
+        import hashlib
+        src = os.path.join(ROOT, "meant_amd", "csrc", "gemm_bf16.hip")
+        self.traffic_stale = bool(doc.get("kernel_source_sha16")) and os.path.exists(src) and \
+            hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] != doc["kernel_source_sha16"]
         tot, n = 0.0, 0
         for _, _, f, key in self.recs:
             if f <= 0:
@@ -564,6 +570,8 @@ def main():
         roofline = {"kernel": "gemm_bf16_nt256s_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic),
+                    "traffic_source": "profiles/r03_nt256s_hbm_traffic.json (rocprofv3 PMC passes; lookup by launched shape)",
+                    "traffic_table_older_than_kernel_source": getattr(timer, "traffic_stale", None),
                     "launches_timed": n, "avg_launch_ms": round(gt / max(n, 1) * 1e3, 4),
                     "avg_launch_gflop": round(gf / max(n, 1) / 1e9, 2),
                     "whole_step_mfma_frac": round(sps / world * flops_per_sample_executed(E) / (PEAK_BF16_TFLOPS * 1e12), 4),
