@@ -64,8 +64,9 @@ int meant_num_cus(void);
  *   "deterministic"    0|1   parameter gradients (dW, dbias) by ordered reductions instead of float atomics: two runs
  *                            on the same inputs are bit-identical; meant_linear_bwd_dw then needs its workspace
  *   "nt_stream"        1|0   streaming 256x256 NT GEMM / one tile per workgroup           (A/B measurements)
- *   "nt_dynamic"       1|0|3 streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements) /
- *                            only XCD 0 uses its own counter, all other tiles go through the steal path (tests)
+ *   "nt_dynamic"       1|0|3|4 streaming GEMM draws tiles from per-XCD counters / fixed walk (A/B measurements) /
+ *                            only XCD 0 uses its own counter, all other tiles go through the steal path (tests) /
+ *                            fixed walk in runs of one A row panel (lab: measured slower)
  *   "nt_grid_cap"      0|n   cap the streaming GEMM's grid at n workgroups (tests: many tiles per workgroup, steals)
  *   "nt_ragged"        1|0   M not a multiple of 256: the streaming GEMM's last row tile is moved up to end at row M (it
  *                            recomputes rows of its neighbour bit-identically) / streaming head + 128 x 128 tail launch

@@ -75,7 +75,7 @@ struct OptionDef { const char* name; const char* env; int dflt; };
 // order == enum meant_option_id (common.h)
 const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"nt_stream", "MEANT_NT_STREAM", 1},           // 0: one-tile-per-workgroup 256x256 NT kernel instead of the streaming one
-    {"nt_dynamic", "MEANT_NT_DYNAMIC", 1},         // 0: fixed persistent tile walk; 1: per-XCD counters; 2: draw but ignore (lab); 3: steal-only (tests)
+    {"nt_dynamic", "MEANT_NT_DYNAMIC", 1},         // 0: fixed persistent tile walk; 1: per-XCD counters; 2: draw but ignore (lab); 3: steal-only (tests); 4: fixed walk in runs of one A row panel (lab)
     {"deterministic", "MEANT_DETERMINISTIC", 0},   // 1: dW / dbias, the embedding gradient (d % 8 == 0, d <= 1024) and the norm gains are bit-reproducible (ordered reductions, no float atomics)
     {"nt_grid_cap", "MEANT_NT_GRID_CAP", 0},       // tests: cap the streaming GEMM's grid (0 = one workgroup per CU)
     {"attn_short", "MEANT_ATTN_SHORT", 1},         // 0: sequences of <= 16 tokens take the tiled flash kernels instead of attn_short.hip

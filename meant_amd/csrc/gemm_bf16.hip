@@ -431,7 +431,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   // workgroup b runs on XCD b % 8 (round-robin dispatch): in every round each XCD takes G/8 consecutive tile ids,
   // i.e. a few rows of tiles that share their A panels and all of W through that XCD's L2
   const int CH = G >> 3, xcd = blockIdx.x & 7;
-  int tile = xcd * CH + (blockIdx.x >> 3);
+  // mode 4 (lab, fixed walk only): a workgroup walks RUNS of ntn consecutive tiles -- all column tiles of one A row panel -- before it
+  // moves G panels on, so that an A panel is requested by one CU nine times in a row rather than by nine CUs at about the same time
+  const int run = mode == 4 ? ntn : 1;
+  auto fixed_next = [&](int t) { return (t + 1) % run != 0 ? t + 1 : t + 1 + (G - 1) * run; };
+  int tile = (xcd * CH + (blockIdx.x >> 3)) * run;
   const bool dynamic = sched != nullptr && nk >= 8;  // the draw travels during K-steps 3..5 and is needed at step nk - 2
   auto leave = [&]() {                                 // last workgroup out resets the counters
     if (sched && threadIdx.x == 0) {
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   const bf16 *pA, *pB, *pAn = nullptr, *pBn = nullptr;      // operand origins of this tile and of the next one
   int64_t m0, n0, m0n = 0, n0n = 0;
   origin(tile, pA, pB, m0, n0);
-  int next = dynamic ? -1 : tile + G;                  // dynamic: unknown until the draw of this tile has come back
+  int next = dynamic ? -1 : fixed_next(tile);          // dynamic: unknown until the draw of this tile has come back
   bool has_next = !dynamic && next < ntiles;
   if (has_next) origin(next, pAn, pBn, m0n, n0n);
   unsigned* mailbox = sched ? &sched->mailbox[blockIdx.x] : nullptr;
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
     tile = next; pA = pAn; pB = pBn; m0 = m0n; n0 = n0n;
     if (dynamic) { next = -1; has_next = false; }
     else {
-      next += G;
+      next = fixed_next(next);
       has_next = next < ntiles;
       if (has_next) origin(next, pAn, pBn, m0n, n0n);
     }
@@ -1201,7 +1205,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       // slot zeroed (last workgroup out), so a slot is never shared by two launches in flight -- by construction, not by
       // distance.  A stream beyond the table's capacity gets the fixed walk (sched = nullptr).  Option nt_dynamic = 0 forces it.
       const int dynmode = meant_opt(MEANT_OPT_NT_DYNAMIC);
-      TileSched* sched = (dynmode != 0 && grid <= 512) ? tile_sched_for(stream) : nullptr;
+      TileSched* sched = (dynmode != 0 && dynmode != 4 && grid <= 512) ? tile_sched_for(stream) : nullptr;
       meant_route_hit(a.rot_qa ? ROUTE_NT256S_ROT : ROUTE_NT256S);
       if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
       else if (ext) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
