@@ -102,3 +102,48 @@ def test_device_batch_loader_cpu_matches_slicing():
     assert len(set(i0) & set(i1)) == 0 and len(i0) == len(i1) == 8
     mean, std = global_mean_std(g)
     assert abs(mean - g.mean()) < 1e-12 and abs(std - g.std()) < 1e-12
+
+
+def _worker_accumulate(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from meant_amd.parallel import GradReducer, shard_batch
+    m = _make_model()
+    red = GradReducer(m.parameters(), bucket_mb=0.05)
+    ids, mask, tgt = _data()
+    lo, hi = shard_batch(4, rank, world)
+    mid = (lo + hi) // 2
+    for _ in range(2):
+        red.prepare()
+        with red.no_sync():                 # first micro-batch: accumulates locally, counts nothing, starts no collective
+            (torch.nn.functional.cross_entropy(m(ids[lo:mid], mask[lo:mid]), tgt[lo:mid]) * 0.5).backward()
+            assert all(b.handle is None for b in red.buckets)
+        (torch.nn.functional.cross_entropy(m(ids[mid:hi], mask[mid:hi]), tgt[mid:hi]) * 0.5).backward()
+        assert any(b.handle is not None for b in red.buckets)
+        red.wait()
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}, out)
+    red.close()
+    n_before = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}
+    torch.nn.functional.cross_entropy(m(ids[lo:hi], mask[lo:hi]), tgt[lo:hi]).backward()      # hooks are gone: plain accumulation, no collective
+    assert all(b.handle is None or b.handle.is_completed() for b in red.buckets)
+    assert any(not torch.equal(n_before[k], p.grad) for k, p in m.named_parameters() if p.requires_grad)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_no_sync_micro_batches_reduce_once_and_close_detaches(tmp_path):
+    """GradReducer.no_sync(): two micro-batches per rank accumulate in the buckets and are reduced by ONE round of collectives,
+    giving the gradients of the whole batch; close() removes the hooks"""
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_worker_accumulate, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    m = _make_model()
+    ids, mask, tgt = _data()
+    torch.nn.functional.cross_entropy(m(ids, mask), tgt).backward()
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(got[k], p.grad, atol=1e-6, rtol=1e-4), k
