@@ -236,7 +236,10 @@ def test_attention_modules_golden(M, O, dev, golden, dtype, name, kind):
                                           # head dims 96 (the reference's default 8 heads: native), 128 (native), 80 (padded to 128
                                           # in the bf16 tier)
                                           ("xpos", 2, 512, 8, 768), ("pixel", 3, 196, 8, 768), ("xpos", 3, 200, 2, 256),
-                                          ("pixel", 2, 130, 1, 128), ("xpos", 2, 100, 4, 320)])
+                                          ("pixel", 2, 130, 1, 128), ("xpos", 2, 100, 4, 320),
+                                          # long sequences: 18 key tiles, and more than 64 (the per-group tile masks no longer fit two
+                                          # 64-bit words: the kernels read the per-tile flags instead)
+                                          ("xpos", 2, 1100, 2, 128), ("xpos", 2, 4200, 2, 128), ("pixel", 1, 4200, 2, 128)])
 def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
     """real head geometry incl. ragged lengths (not multiples of any tile), S=1, fully padded rows"""
     ref, hip = _attn_pair(M, O, kind, H, d, dev)
