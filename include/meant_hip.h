@@ -72,6 +72,8 @@ int meant_num_cus(void);
  *                            recomputes rows of its neighbour bit-identically) / streaming head + 128 x 128 tail launch
  *                            (also what operands that alias the output fall back to)
  *   "attn_short"       1|0   sequences of <= 16 tokens run on the one-wave-per-(group, head) kernels / on the tiled ones
+ *   "nt_split"         0|1   streaming GEMM: all operand DMA issued by waves 0-3 at the top of a K-step / B tiles by waves 0-3 at
+ *                            the top, A tiles by waves 4-7 after their MFMAs
  */
 int meant_set_option(const char* name, int value);
 int meant_get_option(const char* name, int* value);

@@ -80,6 +80,7 @@ const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"nt_grid_cap", "MEANT_NT_GRID_CAP", 0},       // tests: cap the streaming GEMM's grid (0 = one workgroup per CU)
     {"attn_short", "MEANT_ATTN_SHORT", 1},         // 0: sequences of <= 16 tokens take the tiled flash kernels instead of attn_short.hip
     {"nt_ragged", "MEANT_NT_RAGGED", 1},           // 0: ragged M as streaming head + 128 x 128 tail launch instead of the overlapped last row tile
+    {"nt_split", "MEANT_NT_SPLIT", 0},             // 1: streaming GEMM: waves 0-3 issue the B tiles at the top of a K-step, waves 4-7 the A tiles after their MFMAs
 };
 std::atomic<int> g_opt[MEANT_OPT_COUNT];
 std::once_flag g_opt_once;

@@ -453,8 +453,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   // Piece p of a wave starts 8 * pp rows below its first one (pp = p, or p + 12 for the second group), which is a
   // uniform offset; the swizzled 16-byte column of a lane only alternates between two values (c0, c0 ^ 4) with the
   // parity of p.  So a lane keeps two 32-bit offsets per operand and everything else lives in scalar registers.
+  // SPLIT (DBG bit 7): the DMA issue is shared out in TIME as well: waves 0-3 issue the next step's B tile at the top of a K-step and
+  // then compute; their SIMD partners, waves 4-7, compute first and issue the A tile of the step after next when their MFMAs are
+  // done -- the part of the step they used to spend waiting at the barrier.  A `global_load_lds` costs the issuing wave 100-185
+  // cycles in a phase that is also reading fragments (MI355X_MICROARCH.md, LDS-DMA piece issue cost): sixteen of them in front of a
+  // wave's 64 MFMAs were longer than the MFMAs themselves.
+  constexpr bool SPLIT = (DBG & 128) != 0;
   const bool issuer = wave < 4;
-  const int r0 = wave * 32 + (lane >> 3);
+  const int lw = wave & 3;
+  const int r0 = lw * 32 + (lane >> 3);
   const int c0 = (lane & 7) ^ ((r0 >> 1) & 7);
   const unsigned oA[2] = {(unsigned)(r0 * a.lda + c0 * 8), (unsigned)(r0 * a.lda + (c0 ^ 4) * 8)};
   const unsigned oB[2] = {(unsigned)(r0 * a.ldb + c0 * 8), (unsigned)(r0 * a.ldb + (c0 ^ 4) * 8)};
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int pp = p < 4 ? p : p + 12;
-      glds16(base + (int64_t)(8 * pp) * ld + off[p & 1], dst + (wave * 4 + pp) * 1024);
+      glds16(base + (int64_t)(8 * pp) * ld + off[p & 1], dst + (lw * 4 + pp) * 1024);
     }
   };
   auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
@@ -483,12 +490,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
   if (has_next) origin(next, pAn, pBn, m0n, n0n);
   unsigned* mailbox = sched ? &sched->mailbox[blockIdx.x] : nullptr;
 
-  if (issuer) {
+  if (SPLIT) {
+    if (issuer) {
+      stage(pB, oB, a.ldb, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      stage(pA, oA, a.lda, 0);
+      stage(pA + BK, oA, a.lda, 2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+  } else if (issuer) {
     stage(pA, oA, a.lda, 0);
     stage(pB, oB, a.ldb, 1);
     stage(pA + BK, oA, a.lda, 2);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
+  bool first_tile = true;
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -521,8 +538,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       if (issuer && !(DBG & 1)) {
         if (in1) stage(pB + (int64_t)(kt + 1) * BK, oB, a.ldb, s3);
         else if (has_next) stage(pBn, oB, a.ldb, s3);
-        if (in2) stage(pA + (int64_t)(kt + 2) * BK, oA, a.lda, s4);
-        else if (has_next) stage(pAn + (int64_t)(kt + 2 - nk) * BK, oA, a.lda, s4);
+        if (!SPLIT) {
+          if (in2) stage(pA + (int64_t)(kt + 2) * BK, oA, a.lda, s4);
+          else if (has_next) stage(pAn + (int64_t)(kt + 2 - nk) * BK, oA, a.lda, s4);
+        }
       }
       const char* At = smem + sA * T2_BYTES + (wm * 128) * 128;
       const char* Bt = smem + sB * T2_BYTES + (wn * 64) * 128;
@@ -556,7 +575,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
       // Waves 4-7 issue no DMA: all they can have in flight are old output stores and the requests above.  In the three
       // steps of the draw they wait for everything (the stores are long gone by then).
       const bool sched_step = dynamic && !issuer && kt >= 3 && kt <= 5;
-      if ((DBG & 8) && !issuer && !sched_step) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lab: stores of waves 4-7 drain freely
+      if (SPLIT) {
+        // waves 0-3: the B tile issued above (and, older, the previous tile's output stores) must have landed.  Waves 4-7: the A tile
+        // they issued at the end of the PREVIOUS step must have; in a tile's first step that request is older than the sixteen (or
+        // more) output stores of the tile before, which may stay in flight
+        if (!issuer && kt == 0 && !first_tile) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if ((DBG & 8) && !issuer && !sched_step) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lab: stores of waves 4-7 drain freely
       else if (more2 && !sched_step && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       asm volatile("" : "+v"(mail), "+v"(ticket) : : "memory");
@@ -582,6 +607,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
         next = mode == 2 ? (tile + G < ntiles ? tile + G : -1) : (int)got;
         has_next = next >= 0;
         if (has_next) origin(next, pAn, pBn, m0n, n0n);
+      }
+      if (SPLIT && !issuer && !(DBG & 1)) {             // waves 4-7: their MFMAs are done, the A tile of the step after next goes out now
+        if (in2) stage(pA + (int64_t)(kt + 2) * BK, oA, a.lda, s4);
+        else if (has_next) stage(pAn + (int64_t)(kt + 2 - nk) * BK, oA, a.lda, s4);
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -795,6 +824,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
         }
       }
     }
+    first_tile = false;
     if (!has_next) break;
     // the patches live in the ring slots the next step's DMA is about to fill: every wave must be out of them first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1150,6 +1180,9 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, true>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false, true>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, false, false>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, true, false>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, false, true>), RING * T2_BYTES);
   const bool ext = a.row_scale || a.sub || a.bres;
   MEANT_REQUIRE(!a.bres || (a.bres_rows > 0 && (a.N & 7) == 0 && meant_aligned16(a.bres)), MEANT_ERR_ARG, "gemm_bf16_nt: bad broadcast residual");
   MEANT_REQUIRE(!ext || (!a.rot_qa && !(a.epilogue & MEANT_EPI_SIGMOID)), MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: extended epilogue with rotary / sigmoid");
@@ -1207,9 +1240,14 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       const int dynmode = meant_opt(MEANT_OPT_NT_DYNAMIC);
       TileSched* sched = (dynmode != 0 && dynmode != 4 && grid <= 512) ? tile_sched_for(stream) : nullptr;
       meant_route_hit(a.rot_qa ? ROUTE_NT256S_ROT : ROUTE_NT256S);
-      if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
-      else if (ext) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false, true>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
-      else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), dim3((unsigned)grid), dim3(512), RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+      const dim3 g3((unsigned)grid), b3(512);
+      if (meant_opt(MEANT_OPT_NT_SPLIT) != 0) {          // DMA issue split in time between the two waves of a SIMD (see the kernel)
+        if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<128, true>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+        else if (ext) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<128, false, true>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+        else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<128, false>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+      } else if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, true>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+      else if (ext) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false, true>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
+      else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<0, false>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
     } else {
       meant_route_hit(ROUTE_NT256);
       hipLaunchKernelGGL(gemm_bf16_nt256_kernel, dim3((unsigned)(ntm2 * ntn2)), dim3(512), 4 * T2_BYTES, stream, a, (int)ntm2, (int)ntn2);

@@ -36,8 +36,9 @@ def test_checker_flags_a_touched_register():
 def test_tile_draw_registers_stay_untouched_in_flight():
     tool = _tool()
     res = tool.check(tool.compile_to_isa())
-    # three kernel instantiations (plain / rotary / extended epilogue), each with the mailbox read and the counter draw
-    assert len(res) == 6, res
+    # six kernel instantiations (plain / rotary / extended epilogue, each with the DMA issue at the top of the K-step or split in time
+    # between the two waves of a SIMD), each with the mailbox read and the counter draw
+    assert len(res) == 12, res
     for kernel, req, reg, n, bad in res:
         assert bad is None, f"{kernel}: `{req}`: v{reg} touched while in flight by `{bad}`"
         assert n > 100, f"{kernel}: `{req}` is no longer issued ahead of the K-step body ({n} instructions)"
