@@ -104,6 +104,15 @@ int meant_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const f
                       const void* dres, const void* gelu_pre, int dtype, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* ---- RMSNorm, partial / bias forms of the reference class ------- utils/rms_norm.py:44-57 (RMSNorm(d, p, bias))
+ * statistics over the first d_part = int(d * p) elements of a row (1 <= d_part <= d), y = scale * x / (rms_part + eps) + offset
+ * (offset float [d] or NULL).  No MEANT model constructs these; served by the generic one-row-per-wave kernels. */
+int meant_rmsnorm_partial_fwd(const void* x, const float* scale, const float* offset, void* y, float* rinv, int64_t rows,
+                              int64_t d, int64_t d_part, float eps, int dtype, void* stream);
+int meant_rmsnorm_partial_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx, float* dscale,
+                              float* doffset, int64_t rows, int64_t d, int64_t d_part, float eps, int dtype, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- RMSNorm beside the sequence mean-pool -------- utils/rms_norm.py:40-57 + meant/meant.py:74,120 -> :231
  * The last RMSNorm of the last encoder layer has one consumer left once that layer's final Linear is evaluated on the
  * pooled features (mean_s(h W^T + b + x) = mean_s(h) W^T + b + mean_s(x)): the mean over the group_rows tokens of a

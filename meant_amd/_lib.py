@@ -77,6 +77,8 @@ SIGNATURES = {
     "meant_adamw_f32": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _f, _f, _p]),
     "meant_embedding_bwd_sorted": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "meant_embedding_bwd_sorted_range": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p]),
+    "meant_rmsnorm_partial_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _i, _p]),
+    "meant_rmsnorm_partial_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _i, _p, _sz, _p]),
     "meant_rmsnorm_stats": (_i, [_p, _p, _i64, _i64, _f, _i, _p]),
     "meant_rmsnorm_bwd_chain": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _u64, _p, _p, _p, _f, _i64, _p, _p, _i, _p, _sz, _p]),
     "meant_colscale": (_i, [_p, _p, _p, _i64, _i64, _p]),

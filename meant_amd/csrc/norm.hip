@@ -21,14 +21,18 @@ template <> __device__ __forceinline__ float gelu_grad_t<float>(float x) { retur
 template <> __device__ __forceinline__ float gelu_grad_t<bf16>(float x) { return gelu_erf_grad_fast(x); }
 
 
+// d_part / offset: the partial and the bias form of utils/rms_norm.py:44-57 (RMSNorm(d, p, bias=True)): the statistics are taken over
+// the first d_part = int(d p) elements of a row only (d_part == d: the full-width form the MEANT path uses), and `offset` (float [d],
+// may be null) is added to the scaled result.
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                                     T* __restrict__ y, float* __restrict__ rinv_out,
                                                                     int64_t rows, int d, float eps, float drop_p,
-                                                                    uint64_t seed) {
+                                                                    uint64_t seed, int d_part = 0, const float* __restrict__ offset = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
-  const float inv_sqrt_d = rsqrtf((float)d);
+  if (d_part <= 0) d_part = d;
+  const float inv_sqrt_d = rsqrtf((float)d_part);
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const T* xr = x + row * d;
     Vec8<T> v[MAXC];
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __re
       if (ch < nchunk) {
         v[c] = load8<T>(xr + ch * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float f = v[c].get(i); ss += f * f; }
+        for (int i = 0; i < 8; ++i) { const float f = v[c].get(i); ss += ch * 8 + i < d_part ? f * f : 0.f; }
       }
     }
     ss = wave_sum(ss);
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __re
         float km[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
         if (drop_p > 0.f) keep_scale8(drop_p, seed, (uint64_t)row * d + ch * 8, km);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o.set(i, (i < 4 ? g0[i] : g1[i - 4]) * (v[c].get(i) * r) * km[i]);
+        for (int i = 0; i < 8; ++i)
+          o.set(i, (i < 4 ? g0[i] : g1[i - 4]) * (v[c].get(i) * r) * km[i] + (offset ? offset[ch * 8 + i] : 0.f));
         store8<T>(yr + ch * 8, o);
       }
     }
@@ -64,21 +69,25 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const T* __re
 }
 
 // dx_j = r * g_j dy_j  -  x_j * c * r^2 / (n sqrt(d)),  c = sum_i g_i dy_i x_i,  n sqrt(d) = (1/r - eps) d
+// partial form (d_part < d): the statistics see the first d_part elements only, so the second term exists for j < d_part alone and
+// n sqrt(d_part) = (1/r - eps) d_part; partial_off (may be null): per-block column sums of dy, the gradient of the offset
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ rinv, T* __restrict__ dx,
                                                                     float* __restrict__ partial, int64_t rows, int d,
                                                                     float eps, float drop_p, uint64_t seed,
-                                                                    const T* __restrict__ dres, const T* __restrict__ gelu_pre) {
+                                                                    const T* __restrict__ dres, const T* __restrict__ gelu_pre,
+                                                                    int d_part = 0, float* __restrict__ partial_off = nullptr) {
   __shared__ float red[4][512];   // reused per chunk: [wave][64 lanes * 8]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
-  float gacc[MAXC][8];
+  if (d_part <= 0) d_part = d;
+  float gacc[MAXC][8], oacc[MAXC][8];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gacc[c][i] = 0.f;
+    for (int i = 0; i < 8; ++i) { gacc[c][i] = 0.f; oacc[c][i] = 0.f; }
 
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const T* xr = x + row * d;
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
         for (int i = 0; i < 8; ++i) {
           const float dyi = dv.get(i) * km[i];
           const float xi = xv[c].get(i);
+          if (partial_off) oacc[c][i] += dyi;
           gacc[c][i] += dyi * xi * r;
           const float t = (i < 4 ? g0[i] : g1[i - 4]) * dyi;
           gd[c][i] = t;
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
       }
     }
     cdot = wave_sum(cdot);
-    const float nsd = (1.0f / r - eps) * (float)d;          // ||x|| * sqrt(d)
+    const float nsd = (1.0f / r - eps) * (float)d_part;     // ||x_part|| * sqrt(d_part)
     const float k = nsd > 0.f ? cdot * r * r / nsd : 0.f;
     T* dxr = dx + row * d;
 #pragma unroll
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
       if (ch < nchunk) {
         Vec8<T> o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o.set(i, r * gd[c][i] - k * xv[c].get(i));
+        for (int i = 0; i < 8; ++i) o.set(i, r * gd[c][i] - (ch * 8 + i < d_part ? k * xv[c].get(i) : 0.f));
         if (dres) {                                  // gradient arriving through the residual branch that shares x
           const Vec8<T> rv = load8<T>(dres + row * d + ch * 8);
 #pragma unroll
@@ -147,6 +157,23 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const T* __re
         for (int i = 0; i < 8; ++i) {
           const float s = red[0][lane * 8 + i] + red[1][lane * 8 + i] + red[2][lane * 8 + i] + red[3][lane * 8 + i];
           partial[(int64_t)blockIdx.x * d + ch * 8 + i] = s;
+        }
+      }
+    }
+  }
+  if (partial_off) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = oacc[c][i];
+      __syncthreads();
+      if (wave == 0) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            partial_off[(int64_t)blockIdx.x * d + ch * 8 + i] = red[0][lane * 8 + i] + red[1][lane * 8 + i] + red[2][lane * 8 + i] + red[3][lane * 8 + i];
         }
       }
     }
@@ -765,6 +792,40 @@ extern "C" int meant_rmsnorm_bwd(const void* dy, const void* x, const float* sca
                                     (const T*)dres, (const T*)gelu_pre));
   MEANT_LAUNCH_CHECK("rmsnorm_bwd");
   return colsum_launch(workspace, d, dscale, nb, d, MEANT_F32, 0, (hipStream_t)stream);
+}
+
+// ---- partial / bias forms of the reference class (utils/rms_norm.py:44-57); not used by any MEANT model, generic kernels ----
+extern "C" int meant_rmsnorm_partial_fwd(const void* x, const float* scale, const float* offset, void* y, float* rinv, int64_t rows,
+                                         int64_t d, int64_t d_part, float eps, int dtype, void* stream) {
+  MEANT_REQUIRE(x && scale && y && rinv, MEANT_ERR_ARG, "rmsnorm_partial_fwd: null pointer");
+  MEANT_REQUIRE(rows >= 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512 && d_part >= 1 && d_part <= d, MEANT_ERR_UNSUPPORTED,
+                "rmsnorm_partial_fwd: d=%lld must be a multiple of 8 and <= %d, 1 <= d_part=%lld <= d", (long long)d, MAXC * 512, (long long)d_part);
+  MEANT_REQUIRE(meant_aligned16(x) && meant_aligned16(y) && meant_aligned16(scale), MEANT_ERR_ARG, "rmsnorm_partial_fwd: 16-byte alignment");
+  if (rows == 0) return MEANT_OK;
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(rmsnorm_fwd_kernel<T>, dim3(norm_blocks(rows)), dim3(NORM_THREADS), 0, (hipStream_t)stream,
+                                    (const T*)x, scale, (T*)y, rinv, rows, (int)d, eps, 0.f, (uint64_t)0, (int)d_part, offset));
+  MEANT_LAUNCH_CHECK("rmsnorm_partial_fwd");
+  return MEANT_OK;
+}
+
+extern "C" int meant_rmsnorm_partial_bwd(const void* dy, const void* x, const float* scale, const float* rinv, void* dx, float* dscale,
+                                         float* doffset, int64_t rows, int64_t d, int64_t d_part, float eps, int dtype, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(dy && x && scale && rinv && dx && dscale && workspace, MEANT_ERR_ARG, "rmsnorm_partial_bwd: null pointer");
+  MEANT_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= MAXC * 512 && d_part >= 1 && d_part <= d, MEANT_ERR_UNSUPPORTED, "rmsnorm_partial_bwd: unsupported shape");
+  MEANT_REQUIRE(workspace_bytes >= meant_rmsnorm_bwd_ws(rows, d), MEANT_ERR_WORKSPACE, "rmsnorm_partial_bwd: workspace too small");
+  const int nb = norm_blocks(rows);
+  float* part1 = (float*)workspace;
+  float* part2 = doffset ? part1 + (size_t)nb * d : nullptr;
+  DISPATCH_DTYPE(dtype, T,
+                 hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(nb), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const T*)dy,
+                                    (const T*)x, scale, rinv, (T*)dx, part1, rows, (int)d, eps, 0.f, (uint64_t)0,
+                                    (const T*)nullptr, (const T*)nullptr, (int)d_part, part2));
+  MEANT_LAUNCH_CHECK("rmsnorm_partial_bwd");
+  int rc = colsum_launch(part1, d, dscale, nb, d, MEANT_F32, 0, (hipStream_t)stream);
+  if (rc || !doffset) return rc;
+  return colsum_launch(part2, d, doffset, nb, d, MEANT_F32, 0, (hipStream_t)stream);
 }
 
 // ---- pooled forms (the norms whose output or input feeds the sequence mean-pool only) ----

@@ -87,17 +87,25 @@ def resolve_compute_dtype(module: nn.Module, like: Optional[torch.Tensor]) -> to
 
 # ------------------------------------------------------------------------------------------
 class RMSNorm(nn.Module):
-    """utils/rms_norm.py:16-57.  Only the full-width, bias-free form (p=-1, bias=False) that the
-    path uses is implemented natively; the partial/bias variants raise."""
+    """utils/rms_norm.py:16-57.  The full-width, bias-free form (p = -1, bias = False) that every MEANT model uses runs on the packed
+    / fused kernels; the partial form (0 <= p <= 1: statistics over the first int(d p) elements, :44-50) and the bias form (a learned
+    `offset`, :35-37, :54-55) run on the generic one-row-per-wave kernels (meant_rmsnorm_partial_*), without the fusions."""
 
     def __init__(self, d, p=-1., eps=1e-8, bias=False):
         super().__init__()
-        if bias or (0. <= p <= 1.):
-            raise NotImplementedError("meant_amd.RMSNorm: partial (p) / bias variants are not on the MEANT hot path")
         self.eps, self.d, self.p, self.bias = eps, d, p, bias
         self.scale = nn.Parameter(torch.ones(d))
+        if bias:
+            self.offset = nn.Parameter(torch.zeros(d))
 
     def forward(self, x, drop_p: float = 0.0, seed: int = 0):
+        partial = 0. <= self.p <= 1.
+        if partial or self.bias:
+            d_part = int(self.d * self.p) if partial else self.d
+            if d_part < 1:
+                raise ValueError(f"meant_amd.RMSNorm: p = {self.p} leaves no element to take the statistics over (d = {self.d})")
+            y = ops.rmsnorm_partial(x, self.scale, self.offset if self.bias else None, d_part, self.eps)
+            return ops.dropout(y, drop_p, seed) if drop_p > 0.0 else y
         return ops.rmsnorm(x, self.scale, self.eps, drop_p, seed)
 
 

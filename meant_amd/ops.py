@@ -184,6 +184,47 @@ def rmsnorm(x, scale, eps=1e-8, drop_p=0.0, seed=0):
     return _RMSNorm.apply(x, scale, float(eps), float(drop_p), int(seed))
 
 
+class _RMSNormPartial(torch.autograd.Function):
+    """the partial / bias forms of the reference class (utils/rms_norm.py:44-57): statistics over the first d_part elements of a
+    row, optional learned offset.  Not on the MEANT path (every model uses p = -1, bias = False); generic kernels."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, d_part, eps):
+        _need_gpu(x, scale, offset)
+        x = _c(x)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        rinv = torch.empty(rows, device=x.device, dtype=torch.float32)
+        sc = _c(scale.detach().float())
+        off = _c(offset.detach().float()) if offset is not None else None
+        check(lib.meant_rmsnorm_partial_fwd(_p(x), _p(sc), _p(off), _p(y), _p(rinv), rows, d, int(d_part), eps, _dt(x), _stream()),
+              "rmsnorm_partial_fwd")
+        ctx.save_for_backward(x, sc, rinv)
+        ctx.args = (int(d_part), eps, offset is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sc, rinv = ctx.saved_tensors
+        d_part, eps, has_off = ctx.args
+        dy = _c(dy)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dscale = torch.empty(d, device=x.device, dtype=torch.float32)
+        doff = torch.empty(d, device=x.device, dtype=torch.float32) if has_off else None
+        wsb = lib.meant_rmsnorm_bwd_ws(rows, d)
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+        check(lib.meant_rmsnorm_partial_bwd(_p(dy), _p(x), _p(sc), _p(rinv), _p(dx), _p(dscale), _p(doff), rows, d, d_part, eps, _dt(x),
+                                            _p(ws), wsb, _stream()), "rmsnorm_partial_bwd")
+        return dx, dscale, doff, None, None
+
+
+def rmsnorm_partial(x, scale, offset, d_part, eps=1e-8):
+    return _RMSNormPartial.apply(x, scale, offset, int(d_part), float(eps))
+
+
 class _RMSNormFork(torch.autograd.Function):
     """(RMSNorm(x), x): the second output is x itself, to be used as the residual operand further down
     (meant/meant.py:71,74).  Backward receives both gradients and adds the residual one inside the RMSNorm

@@ -103,6 +103,29 @@ def model_case(name, model, inputs, target, full_grads=(), store_inputs=True):
     save(name, **arrs)
 
 
+def gen_rmsnorm_partial(R):
+    """the partial / bias forms of the reference's RMSNorm class (utils/rms_norm.py:44-57): not used by any model, pinned all the same"""
+    rs = np.random.RandomState(11)
+    arrs = {}
+    for tag, d, p, bias in (("a", 256, 0.5, True), ("b", 768, 0.3, False), ("c", 128, 1.0, True), ("d", 64, -1.0, True)):
+        x = rs.standard_normal((2, 3, d)).astype("float32")
+        g = (1 + 0.1 * rs.standard_normal(d)).astype("float32")
+        off = (0.2 * rs.standard_normal(d)).astype("float32")
+        dy = rs.standard_normal((2, 3, d)).astype("float32")
+        n = R.rms.RMSNorm(d, p=p, bias=bias)
+        with torch.no_grad():
+            n.scale.copy_(torch.from_numpy(g))
+            if bias:
+                n.offset.copy_(torch.from_numpy(off))
+        xt = torch.from_numpy(x).requires_grad_()
+        y = n(xt)
+        y.backward(torch.from_numpy(dy))
+        arrs.update({f"{tag}_x": x, f"{tag}_scale": g, f"{tag}_offset": off, f"{tag}_dy": dy, f"{tag}_y": _np(y), f"{tag}_dx": _np(xt.grad),
+                     f"{tag}_dscale": _np(n.scale.grad), f"{tag}_doffset": _np(n.offset.grad) if bias else np.zeros(d, "float32"),
+                     f"{tag}_cfg": np.array([d, p, float(bias)], dtype="float64")})
+    save("rmsnorm_partial_bias", **arrs)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -122,6 +145,8 @@ def main():
     save("rmsnorm_768", x=x, scale=g, dy=dy, y=_np(y), dx=_np(xt.grad), dscale=_np(n.scale.grad),
          kat_in=np.array([1, 2, 3, 4], dtype="float32"),
          kat_out=_np(R.rms.RMSNorm(4)(torch.tensor([1., 2, 3, 4]))))
+
+    gen_rmsnorm_partial(R)
 
     # rotary: xPos (dim 48 of Dh 64, S=512 and S=16) and pixel (dim 32 and 48; N=196)
     xp = R.rot.RotaryEmbedding(dim=48, use_xpos=True)
@@ -424,7 +449,7 @@ def gen_timesformer_mask(R):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
         torch.set_num_threads(8)
-        {"mlm": gen_mlm, "mim": gen_mim, "timesformer": gen_timesformer, "timesformer_mask": gen_timesformer_mask, "timesformer_shift": gen_timesformer_shift, "timesformer_posemb": gen_timesformer_posemb}[sys.argv[2]](load_reference())
+        {"rmsnorm_partial": gen_rmsnorm_partial, "mlm": gen_mlm, "mim": gen_mim, "timesformer": gen_timesformer, "timesformer_mask": gen_timesformer_mask, "timesformer_shift": gen_timesformer_shift, "timesformer_posemb": gen_timesformer_posemb}[sys.argv[2]](load_reference())
     else:
         main()
         R_ = load_reference()

@@ -37,18 +37,27 @@ import torch.nn.functional as F
 class RMSNorm(nn.Module):
     """y = scale * x / (||x||_2 / sqrt(d) + eps); eps is added to the RMS, outside the
     square root (utils/rms_norm.py:52-53).  Only the p<0, bias=False form is on the
-    hot path (utils/rms_norm.py:41-43,57)."""
+    hot path (utils/rms_norm.py:41-43,57).  The partial form (0 <= p <= 1: the statistics are those of the
+    first int(d * p) elements only, :44-50) and the bias form (a learned `offset` added to the result, :35-37,
+    :54-55) are restated too, under the reference's parameter names."""
 
-    def __init__(self, d: int, eps: float = 1e-8):
+    def __init__(self, d: int, p: float = -1., eps: float = 1e-8, bias: bool = False):
         super().__init__()
-        self.d = d
-        self.eps = eps
+        self.d, self.p, self.eps, self.bias = d, p, eps, bias
         self.scale = nn.Parameter(torch.ones(d))
+        if bias:
+            self.offset = nn.Parameter(torch.zeros(d))
 
     def forward(self, x):
-        l2 = torch.sqrt(torch.sum(x * x, dim=-1, keepdim=True))
-        rms = l2 * (self.d ** -0.5)
-        return self.scale * (x / (rms + self.eps))
+        if self.p < 0. or self.p > 1.:
+            part, d_x = x, self.d
+        else:
+            d_x = int(self.d * self.p)
+            part = x[..., :d_x]
+        l2 = torch.sqrt(torch.sum(part * part, dim=-1, keepdim=True))
+        rms = l2 * (d_x ** -0.5)
+        y = self.scale * (x / (rms + self.eps))
+        return y + self.offset if self.bias else y
 
 
 # --------------------------------------------------------------------------------------

@@ -53,6 +53,31 @@ def test_rmsnorm(M, O, dev, golden, dtype, rows, d):
     assert_grad_close(hip.scale.grad, ref.scale.grad, tol["gelem"], "dscale")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_rmsnorm_partial_and_bias_forms_golden(M, dev, golden, dtype, tag):
+    """meant_amd.RMSNorm(d, p, bias) -- the forms of utils/rms_norm.py:44-57 that no MEANT model constructs -- against the reference
+    class's own outputs and gradients (fixture from oracle/gen_golden.py), both tiers; state_dict carries `offset` like the reference"""
+    g = golden("rmsnorm_partial_bias")
+    d, p, bias = int(g[f"{tag}_cfg"][0]), float(g[f"{tag}_cfg"][1]), bool(g[f"{tag}_cfg"][2])
+    hip = M.RMSNorm(d, p=p, bias=bias).to(dev)
+    assert set(hip.state_dict()) == ({"scale", "offset"} if bias else {"scale"})
+    with torch.no_grad():
+        hip.scale.copy_(t(g[f"{tag}_scale"]))
+        if bias:
+            hip.offset.copy_(t(g[f"{tag}_offset"]))
+    x = t(g[f"{tag}_x"]).to(dev).to(dtype).requires_grad_()
+    y = hip(x)
+    y.backward(t(g[f"{tag}_dy"]).to(dev).to(dtype))
+    tol = TOL[dtype]
+    exact = dtype == torch.float32
+    assert_close(y, t(g[f"{tag}_y"]), 1e-5 if exact else tol["out"] * 4, "y")
+    assert_grad_close(x.grad, t(g[f"{tag}_dx"]), 1e-5 if exact else tol["gelem"], "dx")
+    assert_grad_close(hip.scale.grad, t(g[f"{tag}_dscale"]), 1e-4 if exact else tol["gelem"], "dscale")
+    if bias:
+        assert_grad_close(hip.offset.grad, t(g[f"{tag}_doffset"]), 1e-5 if exact else tol["gelem"], "doffset")
+
+
 def test_rmsnorm_golden(M, dev, golden):
     g = golden("rmsnorm_768")
     hip = M.RMSNorm(768).to(dev)

@@ -29,6 +29,27 @@ def test_rmsnorm_kat_and_grads(golden):
     np.testing.assert_allclose(n.scale.grad.numpy(), g["dscale"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_rmsnorm_partial_and_bias_forms(golden, tag):
+    """the partial (statistics over the first int(d p) elements) and bias (learned offset) forms of utils/rms_norm.py:44-57 against the
+    reference class's own outputs and gradients: p = 0.5 + bias, p = 0.3, p = 1.0 + bias, p = -1 + bias"""
+    g = golden("rmsnorm_partial_bias")
+    d, p, bias = int(g[f"{tag}_cfg"][0]), float(g[f"{tag}_cfg"][1]), bool(g[f"{tag}_cfg"][2])
+    n = O.RMSNorm(d, p=p, bias=bias)
+    with torch.no_grad():
+        n.scale.copy_(_t(g[f"{tag}_scale"]))
+        if bias:
+            n.offset.copy_(_t(g[f"{tag}_offset"]))
+    x = _t(g[f"{tag}_x"]).requires_grad_()
+    y = n(x)
+    y.backward(_t(g[f"{tag}_dy"]))
+    np.testing.assert_allclose(y.detach().numpy(), g[f"{tag}_y"], atol=TOL)
+    np.testing.assert_allclose(x.grad.numpy(), g[f"{tag}_dx"], atol=TOL)
+    np.testing.assert_allclose(n.scale.grad.numpy(), g[f"{tag}_dscale"], rtol=1e-4, atol=1e-4)
+    if bias:
+        np.testing.assert_allclose(n.offset.grad.numpy(), g[f"{tag}_doffset"], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("S", [16, 64, 512])
 def test_xpos_rotation(golden, S):
     g = golden("rotary_xpos48")
