@@ -1,0 +1,659 @@
+// K4': single-pass attention backward for the bf16 tier, head dim 64, sequences one workgroup can own
+// (S <= 256, or S <= 512 under the causal mask).  Same semantics as the two-pass form in attn_bf16.hip
+// (meant/attention.py:43-57, meant/xPosAttention.py:41-63: eager softmax(QK^T * scale + mask) V, differentiated), same
+// layouts, same statistics, same rotary adjoint in the epilogue.
+//
+// Why: the two-pass form computes S = QK^T and dP = dO V^T twice (once per pass: 7 products of S x S x 64 and two
+// exponentials per score where the algebra needs 5 and one), because the weights come out of the MFMA with either the key
+// or the query on the lane, and dK/dV want the one, dQ the other.  Here they are computed once, key on the lane, feed dV and
+// dK from registers as before, and dS additionally goes through LDS (written as [key][query] rows, read back by
+// ds_read_b64_tr_b16, i.e. transposed by the hardware) into the dQ product.
+//
+// One workgroup of 8 waves owns a (group, head).  The sequence's keys are worked on in halves of 256 (wave w: keys 32 w ..
+// 32 w + 31 of the half; K and V fragments and the dK / dV accumulators in registers for the whole half), its queries in
+// chunks of 128 that go HBM -> LDS by DMA.  Per chunk:
+//   phase 1  every wave: its 32 keys x the chunk's 128 queries: S, dP, P, dS, dV^T += dO^T P, dK^T += Q^T dS (the tile body of
+//            the two-pass dK/dV kernel), and dS as bf16 into the wave's own 8 KiB region of the panel [256 keys][128 queries];
+//   barrier; the next chunk's Q / dO tiles and its row statistics (m, log2 l, delta = rowsum(dO o O), computed here: there is
+//            no dQ pass that could leave them behind) are requested;
+//   phase 2  wave w: the 32 x 32 block (queries 32 (w >> 1).., head columns 32 (w & 1)..) of dQ^T = K^T dS^T over the half's
+//            256 keys: both operands by transposed reads, K from its LDS image, dS from the panel; blocks of keys that are dead
+//            padding or above the diagonal are skipped;
+//   barrier; dQ block: rotary adjoint, scale, bf16, stored through the wave's panel region.
+// Causal sequences longer than 256: the upper key half (which only queries >= 256 see) goes first and leaves its dQ blocks
+// as fp32 in a scratch buffer, in accumulator order, which the same wave picks up as the starting value when the lower half
+// reaches that chunk -- 64 KiB per (group, head), written and read back by the same CU within microseconds.
+// Per wave the variant of the arithmetic (PLAIN: all 32 keys live, or careful: the reference's step by step) is fixed for
+// a half, as in the two-pass kernel it was per workgroup.
+// LDS: K half 32 KiB | Q, dO chunk 32 KiB | panel 64 KiB | statistics 2 KiB = 130 KiB: one workgroup per CU, two waves per SIMD.
+#include "attn_tiles.h"
+#include <type_traits>
+
+static size_t align256_(size_t x) { return (x + 255) & ~(size_t)255; }
+
+namespace {
+
+constexpr int B1_K = 0;                       // K half: 4 tiles of 64 keys
+constexpr int B1_RING = 4 * TILE_B;           // two slots of one 64-query tile each: [Q | dO | O]
+constexpr int B1_SLOT = 3 * TILE_B;
+constexpr int B1_PANEL = 10 * TILE_B;         // dS panel: 8 wave regions of [query sub-tile 0: 32 keys x 128 B][sub-tile 1]
+constexpr int B1_STATS = 18 * TILE_B;         // [slot][0..127: (m, log2 l) pairs | 128..191: -(m + log2 l) | 192..255: -delta]
+constexpr int B1_LDS = 18 * TILE_B + 2 * 256 * 4;
+constexpr int B1_REGION = 8192;
+#ifndef B1_PIPE
+#define B1_PIPE 2
+#endif
+#ifndef B1_LB
+#define B1_LB 512
+#endif
+
+struct Bwd1Args { BwdArgs b; float* part; };
+#ifdef ATTN_LAB_STAMP
+// lab build only (tools/lab/stamp_bwd1.py): per-workgroup s_memtime sums of wave 0:
+// prologue | phase 1 | wait at the barrier after it | phase 2 | wait at the barrier after it | dQ epilogue | dK dV epilogue | chunks
+constexpr int64_t LAB1_MAX_WG = 20000;
+__device__ unsigned long long g_lab1_stamp[LAB1_MAX_WG * 16];
+__device__ __forceinline__ unsigned long long lab1_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define LAB1(i) { const unsigned long long n__ = lab1_now(); lab_acc[i] += n__ - lab_t; lab_t = n__; }
+#else
+#define LAB1(i)
+#endif
+
+// one 32 (head columns) x 32 (tokens) block, transposed accumulator -> global rows of 32 bf16 through a per-wave patch of 32 x 80 B
+__device__ __forceinline__ void store_transposed1(const f32x16& acc, float mult, char* patch, bf16* __restrict__ dst, int64_t ld, int tok0,
+                                                   int ntok, int lane) {
+  const int t = lane & 31;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[g4 * 4 + e] * mult);
+    const int dh = 8 * g4 + 4 * (lane >> 5);
+    *reinterpret_cast<bf16x4*>(patch + t * 80 + dh * 2) = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = i * 64 + lane;                 // 32 rows x 4 chunks
+    const int r = idx >> 2, c = idx & 3;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(patch + r * 80 + c * 16);
+    if (tok0 + r < ntok) *reinterpret_cast<u32x4*>(dst + (int64_t)(tok0 + r) * ld + c * 8) = v;
+  }
+}
+
+// rotary adjoint (see rotary_adjoint_regs) on one 32-column block starting at head column dh0
+__device__ __forceinline__ void rotary_adjoint_1(f32x16& acc, const float* __restrict__ A, const float* __restrict__ B, int R, int pos,
+                                                 int lane, int dh0) {
+  const float* Ar = A + (int64_t)pos * R;
+  const float* Br = B + (int64_t)pos * R;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int dh = dh0 + 8 * g4 + 4 * (lane >> 5);
+    if (dh < R) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(Ar + dh);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(Br + dh);
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const float d0 = acc[g4 * 4 + e], d1 = acc[g4 * 4 + e + 1];
+        acc[g4 * 4 + e] = av[e] * d0 + bv[e + 1] * d1;
+        acc[g4 * 4 + e + 1] = av[e + 1] * d1 - bv[e] * d0;
+      }
+    }
+  }
+}
+
+// one 1 KiB piece (8 rows) of a 64 x 64 tile: the lane's row-in-tile and swizzled 16-byte column (see make_stage_off, which
+// does the same for a wave's pair of pieces)
+struct PieceOff { unsigned full, last; };
+__device__ __forceinline__ PieceOff make_piece_off(int64_t ld, int nrows, int piece, int lane) {
+  const int last0 = ((nrows - 1) / KV_TILE) * KV_TILE;
+  const int r = piece * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ swz(r);
+  const int rl = min(r, nrows - 1 - last0);                        // (v_min with a scalar operand: a select would park the scalar in a VGPR)
+  return {(unsigned)(r * ld + c * 8), (unsigned)(rl * ld + c * 8)};
+}
+__device__ __forceinline__ void stage_piece(const bf16* __restrict__ g, int64_t ld, int row0, int nrows, char* tile, int piece,
+                                            const PieceOff& po) {
+  const bf16* origin = g + (int64_t)row0 * ld;                       // uniform
+  const bool ragged = row0 + KV_TILE > nrows;                        // uniform
+  glds16(origin + (ragged ? po.last : po.full), tile + piece * 1024);
+}
+// workgroup barrier with the waits chosen by the caller (the compiler's own __syncthreads() waits for vmcnt(0), which would
+// drain a tile requested a moment ago); the "memory" clobber keeps the compiler from moving LDS / global accesses across it
+#define B1_BARRIER(WAITS) asm volatile("s_waitcnt " WAITS "\n\ts_barrier" ::: "memory")
+
+__global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
+  const BwdArgs& a = args.b;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = 4;
+  float* stats = reinterpret_cast<float*>(smem + B1_STATS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S, H = a.H, D = H * DH;
+  const int64_t ld = 3 * (int64_t)D;
+  int x_, h, g;
+  if (!attn_item(1, H, a.G, x_, h, g)) return;
+  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;  // Q columns of this head; K at + D, V at + 2 D
+  const bf16* dO = a.dout + (int64_t)g * S * D + h * DH;
+  const bf16* Og = a.o + (int64_t)g * S * D + h * DH;
+  const float* lse = a.lse + ((int64_t)g * H + h) * S * 2;
+  bf16* dqkv = a.dqkv + (int64_t)g * S * ld + h * DH;
+  const int ntile = (S + KV_TILE - 1) / KV_TILE;
+  uint64_t sp, sk;                                           // per 64-key tile: needs the bias / tail path; dead padding
+  sload_masks(a.masks + 2 * (int64_t)g, sp, sk);
+  const float c1 = a.scale * LOG2E;
+  const int nhalf = (S + 255) >> 8, nchunk = (S + 127) >> 7;
+  const unsigned troff0 = make_troff(lane).o[0][0];         // the other three: constant bit flips of this one (see tile())
+  const unsigned foff0 = (unsigned)((lane & 31) * 128 + (((lane >> 5) ^ swz(lane & 31)) << 4));
+  char* myreg = smem + B1_PANEL + wave * B1_REGION;        // this wave's panel region, and its patch once the panel is done with
+  const unsigned prow = lds_addr(myreg) + (lane & 31) * 128 + 8 * (lane >> 5);
+  const unsigned pswz = (unsigned)swz(lane & 31) << 4;
+  float* part_w = args.part ? args.part + (((int64_t)g * H + h) * 2 * 8 + wave) * 1024 : nullptr;   // uniform; + (c - 2) * 8192 + i * 256 + 4 lane
+  bool part_valid = false;
+#ifdef ATTN_LAB_STAMP
+  unsigned long long lab_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long lab_t = lab1_now();
+#endif
+
+  // request the tq-th 64-query tile of chunk c into ring slot tq: this wave's piece (rows 8 w .. 8 w + 7) of Q, dO and O, and
+  // the (m, log2 l) pairs of those rows.  The lane-derived offsets are recomputed here on purpose (from a value the compiler
+  // cannot see through): hoisted out of the chunk loop they would sit in registers across phase 1, which has none to spare.
+  auto issue_tile = [&](int c, int tq) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int row0 = c * 128 + tq * 64;
+    char* slot = smem + B1_RING + tq * B1_SLOT;
+    const PieceOff pq = make_piece_off(ld, S, wave, ln), pd = make_piece_off(D, S, wave, ln);
+    stage_piece(base, ld, row0, S, slot, wave, pq);
+    stage_piece(dO, D, row0, S, slot + TILE_B, wave, pd);
+    stage_piece(Og, D, row0, S, slot + 2 * TILE_B, wave, pd);
+    if (ln < 16) {
+      int i = 2 * (row0 + 8 * wave) + ln;
+      i = min(i, 2 * S - 1);
+      glds4(lse + i, stats + tq * 256 + 16 * wave);
+    }
+  };
+  // statistics of the tile in slot tq, from LDS, for the 8 rows this wave requested itself (its own vmcnt wait covers them):
+  // delta = rowsum(dO o O) (8 lanes per row), -(m + log2 l)
+  auto stat_step = [&](int tq) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const char* slot = smem + B1_RING + tq * B1_SLOT;
+    float* st = stats + tq * 256;
+    const int r = 8 * wave + (ln >> 3);
+    const int off = r * 128 + (((ln & 7) ^ swz(r)) << 4);
+    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(slot + TILE_B + off);
+    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slot + 2 * TILE_B + off);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d += (float)dv[j] * (float)ov[j];
+    // sum over the row's 8 lanes in the DPP network (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror), not through ds_bpermute
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xf, 0xf, true));
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xf, 0xf, true));
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xf, 0xf, true));
+    if ((ln & 7) == 0) {
+      const float2 ml = *reinterpret_cast<const float2*>(st + 2 * r);
+      st[128 + r] = -(ml.x + ml.y);
+      st[192 + r] = -d;
+    }
+  };
+
+  auto half = [&](int hk, auto PLAIN_T) {
+    constexpr bool PLAIN = decltype(PLAIN_T)::value;
+    const int kh0 = hk * 256, key0 = kh0 + wave * 32, mykey = key0 + (lane & 31);
+    const int krow = min(mykey, S - 1);
+    const bool wave_live = uni(key0 < S && !((sk >> (key0 >> 6)) & 1));
+    unsigned deadm = 0;                                      // bit kb: keys kh0 + 32 kb .. + 31 contribute nothing (dead padding / past S)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      const int k0 = kh0 + 32 * kb;
+      if (k0 >= S || ((sk >> (k0 >> 6)) & 1)) deadm |= 1u << kb;
+    }
+    const int c0 = a.causal ? 2 * hk : 0, c1l = nchunk - 1;
+
+    // K half (piece w of each of its tiles) and the first chunk's tiles on their way before anything else
+    {
+      const PieceOff pk = make_piece_off(ld, S, wave, lane);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kh0 + 64 * kt < S) stage_piece(base + D, ld, kh0 + 64 * kt, S, smem + B1_K + kt * TILE_B, wave, pk);
+    }
+    issue_tile(c0, 0);
+    if (c0 * 128 + 64 < S) issue_tile(c0, 1);
+    bf16x8 kf[KS], vf[KS];
+    {
+      const bf16* kp = base + (int64_t)krow * ld + D + 8 * (lane >> 5);
+      const bf16* vp = kp + D;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
+      }
+    }
+    float bkey = 0.f;                                      // key bias (log2 units; -inf past S); zero by construction when PLAIN
+    if (!PLAIN) bkey = mykey < ntile * KV_TILE ? a.bias2[(int64_t)g * ntile * KV_TILE + mykey] : -INFINITY;
+    f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dkacc[b][e] = 0.f; dvacc[b][e] = 0.f; }
+
+    // ---- phase 1 body: the 64-query tile in ring slot tq against this wave's 32 keys ----
+    auto tile = [&](int qt0, int tq) {
+      // the per-lane offsets pass through an opaque copy at every use site: what is derived from them (some 50 LDS addresses
+      // per tile, each one add or xor away) stays inside the loop instead of being hoisted to the top of the kernel and spilled
+      unsigned pswz_l = pswz, prow_l = prow, fo0 = foff0, tr0 = troff0;
+      asm volatile("" : "+v"(pswz_l), "+v"(prow_l), "+v"(fo0), "+v"(tr0));
+      // the other three row-fragment offsets and transposed-read offsets differ from the first by constant bit flips (the
+      // swizzle is an XOR of address bits 4-6 and every tile starts on a 128-byte boundary): one register each, not four
+      const TrOff troff = {{{tr0, tr0 ^ 64u}, {tr0 ^ (1024u | 32u), tr0 ^ (1024u | 32u | 64u)}}};
+      const float* st = stats + tq * 256;
+      const char* Qb = smem + B1_RING + tq * B1_SLOT;
+      const char* dOb = Qb + TILE_B;
+      const unsigned pbase = prow_l + tq * 4096;
+      const unsigned pswz = pswz_l;
+      const int qrow0 = 4 * (lane >> 5);
+      f32x16 sacc[2], dpacc[2];
+      const unsigned fb0 = lds_addr(Qb) + fo0;
+      const unsigned fbase[4] = {fb0, fb0 ^ 32u, fb0 ^ 64u, fb0 ^ 96u};
+      auto frags = [&](auto SQ, bf16x8 (&qv)[KS], bf16x8 (&dv)[KS]) {
+        constexpr int sq = decltype(SQ)::value;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          qv[ks] = lds_frag<sq * 4096>(fbase[ks]);
+          dv[ks] = lds_frag<sq * 4096 + TILE_B>(fbase[ks]);
+        }
+      };
+      auto scores = [&](auto SQ, auto YOUNGER, bf16x8 (&qv)[KS], bf16x8 (&dv)[KS]) {
+        constexpr int sq = decltype(SQ)::value;
+        constexpr int younger = decltype(YOUNGER)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[sq][e] = 0.f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(st + 192 + 32 * sq + qrow0 + 8 * g4);
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) dpacc[sq][g4 * 4 + e4] = nd[e4];
+        }
+        auto kstep = [&](auto KSI) {
+          constexpr int ks = decltype(KSI)::value;
+          lds_wait_frags<(younger + 2 * (KS - 1 - ks) > 15 ? 15 : younger + 2 * (KS - 1 - ks))>(qv[ks], dv[ks]);
+          sacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qv[ks], kf[ks], sacc[sq], 0, 0, 0);
+          dpacc[sq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv[ks], vf[ks], dpacc[sq], 0, 0, 0);
+        };
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
+      };
+      auto weights = [&](auto SQ, bf16x8 (&pf)[2], bf16x8 (&dsf)[2]) {
+        constexpr int sq = decltype(SQ)::value;
+        if (PLAIN) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 nm = *reinterpret_cast<const f32x4*>(st + 128 + 32 * sq + qrow0 + 8 * g4);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) sacc[sq][g4 * 4 + e4] = __builtin_amdgcn_exp2f(fmaf(sacc[sq][g4 * 4 + e4], c1, nm[e4]));
+          }
+        } else {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 ml0 = *reinterpret_cast<const f32x4*>(st + 2 * (32 * sq + qrow0 + 8 * g4));
+            const f32x4 ml1 = *reinterpret_cast<const f32x4*>(st + 2 * (32 * sq + qrow0 + 8 * g4) + 4);
+            const float mv[4] = {ml0[0], ml0[2], ml1[0], ml1[2]};
+            const float lv[4] = {ml0[1], ml0[3], ml1[1], ml1[3]};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const float tv = fmaf(sacc[sq][g4 * 4 + e4], c1, bkey);
+              sacc[sq][g4 * 4 + e4] = __builtin_amdgcn_exp2f((tv - mv[e4]) - lv[e4]);
+            }
+          }
+        }
+        if (uni(((a.causal != 0) & (qt0 + 32 * sq < key0 + 31)) | (qt0 + 32 * sq + 32 > S))) {
+          const int qvis = a.causal ? mykey : -1;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int q = qt0 + 32 * sq + qrow0 + 8 * (e >> 2) + (e & 3);
+            sacc[sq][e] = (q < qvis || q >= S) ? 0.f : sacc[sq][e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dpacc[sq][e] *= sacc[sq][e];    // dS / scale  (dP was started at -delta)
+        acc_to_frags(sacc[sq], pf[0], pf[1]);
+        acc_to_frags(dpacc[sq], dsf[0], dsf[1]);
+        // dS^T rows of this lane's key into the panel: 4 x 4 consecutive queries (8 bytes each)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const u32x4 w = __builtin_bit_cast(u32x4, dsf[g4 >> 1]);
+          const u32x2 v = {w[2 * (g4 & 1)], w[2 * (g4 & 1) + 1]};
+          const unsigned addr = pbase + ((unsigned)((4 * sq + g4) << 4) ^ pswz);
+          asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        }
+      };
+      auto products = [&](auto SQ, const bf16x8 (&pf)[2], const bf16x8 (&dsf)[2]) {
+        constexpr int sq = decltype(SQ)::value;
+        const unsigned qaddr = lds_addr(Qb) + sq * 4096, doaddr = lds_addr(dOb) + sq * 4096;
+        u32x2 dlo[2][2], dhi[2][2], qlo[2][2], qhi[2][2];
+        tr_issue<0>(doaddr, troff, 0, dlo[0][0], dhi[0][0]);
+        tr_issue<0>(doaddr, troff, 1, dlo[0][1], dhi[0][1]);
+        tr_issue<16>(doaddr, troff, 0, dlo[1][0], dhi[1][0]);
+        tr_issue<16>(doaddr, troff, 1, dlo[1][1], dhi[1][1]);
+        tr_issue<0>(qaddr, troff, 0, qlo[0][0], qhi[0][0]);
+        tr_issue<0>(qaddr, troff, 1, qlo[0][1], qhi[0][1]);
+        tr_issue<16>(qaddr, troff, 0, qlo[1][0], qhi[1][0]);
+        tr_issue<16>(qaddr, troff, 1, qlo[1][1], qhi[1][1]);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dlo[0][0]), "+v"(dhi[0][0]), "+v"(dlo[0][1]), "+v"(dhi[0][1]), "+v"(dlo[1][0]), "+v"(dhi[1][0]), "+v"(dlo[1][1]),
+                       "+v"(dhi[1][1]), "+v"(qlo[0][0]), "+v"(qhi[0][0]), "+v"(qlo[0][1]), "+v"(qhi[0][1]), "+v"(qlo[1][0]), "+v"(qhi[1][0]),
+                       "+v"(qlo[1][1]), "+v"(qhi[1][1]));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            dvacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(dlo[s2][b], dhi[s2][b]), pf[s2], dvacc[b], 0, 0, 0);
+            dkacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(qlo[s2][b], qhi[s2][b]), dsf[s2], dkacc[b], 0, 0, 0);
+          }
+      };
+      const std::integral_constant<int, 0> B0{};
+      const std::integral_constant<int, 1> B1{};
+      const std::integral_constant<int, 0> NONE{};
+      const std::integral_constant<int, 2 * KS> BLOCK{};
+      bf16x8 pf0[2], dsf0[2], pf1[2], dsf1[2];
+      bf16x8 q0[KS], d0[KS], q1[KS], d1[KS];
+#if B1_PIPE == 2
+      frags(B0, q0, d0);
+      frags(B1, q1, d1);
+      scores(B0, BLOCK, q0, d0);
+      __builtin_amdgcn_sched_barrier(0);
+      scores(B1, NONE, q1, d1);
+      weights(B0, pf0, dsf0);
+      __builtin_amdgcn_sched_barrier(0);
+      products(B0, pf0, dsf0);
+      weights(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+      products(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+#elif B1_PIPE == 1
+      frags(B0, q0, d0);
+      scores(B0, NONE, q0, d0);
+      __builtin_amdgcn_sched_barrier(0);
+      frags(B1, q1, d1);
+      scores(B1, NONE, q1, d1);
+      weights(B0, pf0, dsf0);
+      __builtin_amdgcn_sched_barrier(0);
+      products(B0, pf0, dsf0);
+      weights(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+      products(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+#else
+      frags(B0, q0, d0);
+      scores(B0, NONE, q0, d0);
+      weights(B0, pf0, dsf0);
+      products(B0, pf0, dsf0);
+      __builtin_amdgcn_sched_barrier(0);
+      frags(B1, q1, d1);
+      scores(B1, NONE, q1, d1);
+      weights(B1, pf1, dsf1);
+      products(B1, pf1, dsf1);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+
+    LAB1(8)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LAB1(9)
+    // naming the fragments here makes the compiler place its own wait for their loads HERE: otherwise it cannot rule out that
+    // they are still pending at the loop head and puts a vmcnt(0) in front of the first MFMA of every tile, which drains the
+    // tile requested a moment before
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+    asm volatile("" : "+v"(bkey));
+    stat_step(0);
+    LAB1(10)
+    B1_BARRIER("lgkmcnt(0)");                                // K half, tile (c0, 0) and its statistics: in LDS
+    LAB1(0)
+#pragma unroll 1
+    for (int c = c0; c <= c1l; ++c) {
+      const bool have_b = c * 128 + 64 < S, more = c < c1l;  // uniform
+      // the slot index goes through an opaque scalar: with a literal 0 / 1 every LDS address of the tile body is loop-invariant,
+      // hipcc hoists ~50 of them out of the chunk loop and spills them (and K / V fragments) across phase 1
+      int slot_a = 0, slot_b = 1;
+      asm volatile("" : "+s"(slot_a), "+s"(slot_b));
+      // ---- phase 1, first tile (slot 0) ----
+      if (wave_live && (!a.causal || c * 128 + 63 >= key0)) tile(c * 128, slot_a);
+      LAB1(1)
+      if (have_b) {                                          // the second tile was requested a phase ago: its statistics
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LAB1(12)
+        stat_step(1);
+        LAB1(13)
+      }
+      B1_BARRIER("vmcnt(0) lgkmcnt(0)");                     // slot 0 free; slot 1 and its statistics visible
+      LAB1(2)
+      if (more) issue_tile(c + 1, 0);
+      // ---- phase 1, second tile (slot 1) ----
+      if (have_b && wave_live && (!a.causal || c * 128 + 127 >= key0)) tile(c * 128 + 64, slot_b);
+      LAB1(1)
+      B1_BARRIER("lgkmcnt(0)");                              // panel complete; slot 1 free
+      LAB1(11)
+      // ---- phase 2 ----
+      const int qt = wave >> 1, bh = wave & 1;
+      const int q0b = c * 128 + 32 * qt;
+      const bool p2 = q0b < S;                               // uniform
+      const bool take_part = p2 && hk == 0 && part_valid && c >= 2;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      f32x4 pv[4];                                           // the upper half's block of this chunk (added at the end: no wait here)
+      f32x4 rav[4], rbv[4];                                  // rotary rows of this lane's query, for the epilogue
+      int qpos = q0b + (lane & 31);
+      qpos = min(qpos, S - 1);
+      if (take_part) {
+        const float* pp = part_w + (c - 2) * 8192 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + i * 256);
+      }
+      const bool rot_q = p2 && hk == 0 && a.rot.qa != nullptr;
+      {
+        // loaded on every path (from the start of the q|k|v buffer when there is nothing to rotate) and named after the wait
+        // below on every path: a load under one branch and its use under another would leave the compiler unable to tell that
+        // the wait has happened, and it would put a vmcnt(0) in front of the epilogue, behind the request for the next tile
+        const int Rr = rot_q ? a.rot.R : 4;
+        const float* Ar = rot_q ? a.rot.qa + (int64_t)qpos * Rr : reinterpret_cast<const float*>(a.qkv);
+        const float* Br = rot_q ? a.rot.qb + (int64_t)qpos * Rr : reinterpret_cast<const float*>(a.qkv);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int dh = 32 * bh + 8 * g4 + 4 * (lane >> 5);
+          const int dhc = dh < Rr ? dh : 0;                  // columns past the rotary width: loaded from column 0, not used
+          rav[g4] = *reinterpret_cast<const f32x4*>(Ar + dhc);
+          rbv[g4] = *reinterpret_cast<const f32x4*>(Br + dhc);
+        }
+      }
+      if (p2) {
+        const unsigned kaddr = lds_addr(smem + B1_K), paddr = lds_addr(smem + B1_PANEL) + (qt >> 1) * 4096;
+        const int b = qt & 1;
+        unsigned livem = ~deadm & 0xffu;
+        if (a.causal) {
+          const int kbmax = (q0b + 31 - kh0) >> 5;           // last 32-key block any query of this block sees
+          if (kbmax < 7) livem &= (2u << kbmax) - 1u;
+        }
+        // per-lane offsets of the transposed reads for this wave's column blocks (selects, not indexed: an indexed TrOff lives in scratch)
+        unsigned tr0 = troff0;
+        asm volatile("" : "+v"(tr0));
+        const unsigned ka0 = kaddr + (tr0 ^ (bh ? 64u : 0u)), ka1 = ka0 ^ (1024u | 32u);
+        const unsigned pa0 = paddr + (tr0 ^ (b ? 64u : 0u)), pa1 = pa0 ^ (1024u | 32u);
+        // key blocks in ascending order, the reads of the next live block issued before the products of the current one
+        struct KP { u32x2 alo[2], ahi[2], blo[2], bhi[2]; };
+        auto issue = [&](int kb, KP& r) {                    // rows 32 (kb & 1).. of K tile kb >> 1 = byte kb * 4096; panel region kb
+          const unsigned ka = ka0 + kb * 4096, kc = ka1 + kb * 4096, pa = pa0 + kb * B1_REGION, pc = pa1 + kb * B1_REGION;
+          r.alo[0] = lds_read_tr16<0>(ka);
+          r.ahi[0] = lds_read_tr16<0>(kc);
+          r.blo[0] = lds_read_tr16<0>(pa);
+          r.bhi[0] = lds_read_tr16<0>(pc);
+          r.alo[1] = lds_read_tr16<16 * 128>(ka);
+          r.ahi[1] = lds_read_tr16<16 * 128>(kc);
+          r.blo[1] = lds_read_tr16<16 * 128>(pa);
+          r.bhi[1] = lds_read_tr16<16 * 128>(pc);
+        };
+        auto mma = [&](auto YOUNGER, KP& r) {
+          constexpr int younger = decltype(YOUNGER)::value;
+          asm volatile("s_waitcnt lgkmcnt(%8)"
+                       : "+v"(r.alo[0]), "+v"(r.ahi[0]), "+v"(r.blo[0]), "+v"(r.bhi[0]), "+v"(r.alo[1]), "+v"(r.ahi[1]), "+v"(r.blo[1]), "+v"(r.bhi[1])
+                       : "n"(younger));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(r.alo[0], r.ahi[0]), pack_tr(r.blo[0], r.bhi[0]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(r.alo[1], r.ahi[1]), pack_tr(r.blo[1], r.bhi[1]), acc, 0, 0, 0);
+        };
+        const std::integral_constant<int, 8> NEXT{};
+        const std::integral_constant<int, 0> LAST{};
+        unsigned m = livem;
+        if (m) {
+          KP ra, rb;
+          issue(__builtin_ctz(m), ra);
+          m &= m - 1;
+          for (;;) {
+            if (!m) { mma(LAST, ra); break; }
+            issue(__builtin_ctz(m), rb);
+            m &= m - 1;
+            mma(NEXT, ra);
+            if (!m) { mma(LAST, rb); break; }
+            issue(__builtin_ctz(m), ra);
+            m &= m - 1;
+            mma(NEXT, rb);
+          }
+        }
+      }
+      LAB1(3)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile (c + 1, 0), requested a phase ago; the partial block; the rotary rows
+      LAB1(14)
+      // (named here so that the compiler's own waits for these loads land here, not behind the request for tile (c + 1, 1) below)
+      if (take_part) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[4 * i + e] += pv[i][e];
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(rav[g4]), "+v"(rbv[g4]));
+      if (p2 && hk != 0) {                                   // upper key half: leave the block for the lower half's pass over this chunk
+        float* pp = part_w + (c - 2) * 8192 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 v = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+          *reinterpret_cast<f32x4*>(pp + i * 256) = v;
+        }
+      }
+      if (more) {
+        stat_step(0);
+        if ((c + 1) * 128 + 64 < S) issue_tile(c + 1, 1);
+      }
+      LAB1(15)
+      B1_BARRIER("lgkmcnt(0)");                              // panel free; tile (c + 1, 0) and its statistics visible
+      LAB1(4)
+      if (p2 && hk == 0) {
+        if (rot_q) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int dh = 32 * bh + 8 * g4 + 4 * (lane >> 5);
+            if (dh < a.rot.R) {
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                const float d0 = acc[g4 * 4 + e], d1 = acc[g4 * 4 + e + 1];
+                acc[g4 * 4 + e] = rav[g4][e] * d0 + rbv[g4][e + 1] * d1;
+                acc[g4 * 4 + e + 1] = rav[g4][e + 1] * d1 - rbv[g4][e] * d0;
+              }
+            }
+          }
+        }
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        store_transposed1(acc, a.scale, myreg, dqkv + 32 * bh, ld, q0b, S, ln);
+      }
+      LAB1(5)
+#ifdef ATTN_LAB_STAMP
+      lab_acc[7] += 1;
+#endif
+    }
+    // ---- dV, dK of this wave's 32 keys ----
+    if (wave_live) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int krow_e = min(key0 + (ln & 31), S - 1);     // recomputed: nothing per-lane of the epilogue lives across the chunk loop
+      store_transposed(dvacc, 1.0f, myreg, dqkv + 2 * D, ld, key0, S, ln, 2);
+      if (a.rot.ka) rotary_adjoint_regs(dkacc, a.rot.ka, a.rot.kb, a.rot.R, krow_e, ln);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      store_transposed(dkacc, a.scale, myreg, dqkv + D, ld, key0, S, ln, 2);
+    } else if (key0 < S) {                                   // dead padding: exact zeros
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      for (int idx = lane; idx < 32 * 16; idx += 64) {
+        const int row = idx >> 4, cc = idx & 15;
+        if (key0 + row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)(key0 + row) * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    LAB1(6)
+  };
+
+#pragma unroll 1
+  for (int hk = nhalf - 1; hk >= 0; --hk) {
+    const int key0 = hk * 256 + wave * 32;
+    bool half_dead = true;
+    for (int t = hk * 4; t < hk * 4 + 4 && t < ntile; ++t) half_dead = half_dead && ((sk >> t) & 1);
+    if (uni(half_dead && hk > 0)) {                          // nothing in the upper half is alive: zeros, and no partial dQ either (the lower
+                                                             // half always runs: it is the one that writes dQ)
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      for (int idx = lane; idx < 32 * 16; idx += 64) {
+        const int row = idx >> 4, cc = idx & 15;
+        if (key0 + row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)(key0 + row) * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
+      }
+      continue;
+    }
+    const bool wave_plain = uni(key0 + 32 <= S && !((sp >> (key0 >> 6)) & 1) && !((sk >> (key0 >> 6)) & 1));
+    if (wave_plain) half(hk, std::true_type{});
+    else half(hk, std::false_type{});
+    part_valid = hk == 1;
+  }
+#ifdef ATTN_LAB_STAMP
+  if (tid == 0 && blockIdx.x < LAB1_MAX_WG)
+    for (int i = 0; i < 16; ++i) g_lab1_stamp[blockIdx.x * 16 + i] = lab_acc[i];
+#endif
+}
+
+}  // namespace
+
+#ifdef ATTN_LAB_STAMP
+extern "C" int meant_lab_stamps1(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lab1_stamp), bytes < sizeof(g_lab1_stamp) ? bytes : sizeof(g_lab1_stamp));
+}
+#endif
+
+size_t attn_bwd1_ws(int64_t G, int64_t S, int H, int Dh) {
+  if (Dh != DH || S <= 256 || S > 512) return 0;
+  return align256_((size_t)G * H * 2 * 8 * 1024 * sizeof(float));
+}
+
+bool attn_bwd1_ok(int64_t S, int Dh, int causal) {
+  return meant_opt(MEANT_OPT_ATTN_BWD1) != 0 && Dh == DH && S > 0 && (S <= 256 || (causal && S <= 512));
+}
+
+// masks: the packed tile masks of attn_pack_flags_kernel (always present here: S <= 512 is at most 8 tiles); part: attn_bwd1_ws bytes
+int attn_bwd1_launch(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* bias2, const int* flags,
+                     const uint64_t* masks, bf16* dqkv, float* part, int64_t G, int64_t S, int H, float scale, int causal, RotTables rot,
+                     hipStream_t stream) {
+  MEANT_REQUIRE(masks != nullptr, MEANT_ERR_ARG, "attn_bwd1: packed tile masks missing");
+  MEANT_REQUIRE(S <= 256 || part != nullptr, MEANT_ERR_WORKSPACE, "attn_bwd1: partial-dQ scratch missing");
+  Bwd1Args a{{qkv, o, dout, lse, bias2, flags, dqkv, nullptr, masks, 0, (int)S, H, scale, causal, (int)G, (int)ceil_div(S, 128), rot}, part};
+  MEANT_RAISE_LDS(attn_bwd1_kernel, B1_LDS);
+  meant_route_hit(ROUTE_ATTN_BWD1);
+  hipLaunchKernelGGL(attn_bwd1_kernel, dim3(attn_grid(1, H, G)), dim3(512), B1_LDS, stream, a);
+  MEANT_LAUNCH_CHECK("attn_bwd1");
+  return MEANT_OK;
+}

@@ -50,14 +50,14 @@ int meant_raise_dyn_lds(const void* kernel, int bytes);
   } while (0)
 
 enum meant_option_id {
-  MEANT_OPT_NT_STREAM = 0, MEANT_OPT_NT_DYNAMIC, MEANT_OPT_DETERMINISTIC, MEANT_OPT_NT_GRID_CAP, MEANT_OPT_ATTN_SHORT, MEANT_OPT_NT_RAGGED, MEANT_OPT_NT_SPLIT, MEANT_OPT_COUNT
+  MEANT_OPT_NT_STREAM = 0, MEANT_OPT_NT_DYNAMIC, MEANT_OPT_DETERMINISTIC, MEANT_OPT_NT_GRID_CAP, MEANT_OPT_ATTN_SHORT, MEANT_OPT_NT_RAGGED, MEANT_OPT_NT_SPLIT, MEANT_OPT_ATTN_BWD1, MEANT_OPT_COUNT
 };
 int meant_opt(int id);
 
 enum meant_route_id {
   ROUTE_NT128 = 0, ROUTE_NT256, ROUTE_NT256S, ROUTE_NT256S_ROT, ROUTE_NT_SPLIT, ROUTE_TN128, ROUTE_TN256, ROUTE_TN256_DET, ROUTE_TN_TAIL,
   ROUTE_GEMM_F32, ROUTE_ATTN_FWD, ROUTE_ATTN_FWD_D128, ROUTE_ATTN_FWD_D96, ROUTE_ATTN_BWD,
-  ROUTE_ATTN_BWD_D128, ROUTE_ATTN_BWD_D96, ROUTE_ATTN_GENERIC, ROUTE_ATTN_CLS, ROUTE_ATTN_SHORT, ROUTE_NT_OVERLAP, MEANT_ROUTE_COUNT
+  ROUTE_ATTN_BWD_D128, ROUTE_ATTN_BWD_D96, ROUTE_ATTN_GENERIC, ROUTE_ATTN_CLS, ROUTE_ATTN_SHORT, ROUTE_NT_OVERLAP, ROUTE_ATTN_BWD1, MEANT_ROUTE_COUNT
 };
 void meant_route_hit(int route);
 

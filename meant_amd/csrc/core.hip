@@ -81,6 +81,7 @@ const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"attn_short", "MEANT_ATTN_SHORT", 1},         // 0: sequences of <= 16 tokens take the tiled flash kernels instead of attn_short.hip
     {"nt_ragged", "MEANT_NT_RAGGED", 1},           // 0: ragged M as streaming head + 128 x 128 tail launch instead of the overlapped last row tile
     {"nt_split", "MEANT_NT_SPLIT", 0},             // 1: streaming GEMM: waves 0-3 issue the B tiles at the top of a K-step, waves 4-7 the A tiles after their MFMAs
+    {"attn_bwd1", "MEANT_ATTN_BWD1", 1},           // 0: attention backward always as two passes (dQ, then dK / dV) instead of the single-pass kernel where it applies
 };
 std::atomic<int> g_opt[MEANT_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -126,7 +127,7 @@ namespace {
 const char* const k_routes[MEANT_ROUTE_COUNT] = {
     "nt128", "nt256", "nt256s", "nt256s_rot", "nt_split", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32",
     "attn_fwd", "attn_fwd_d128", "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96",
-    "attn_generic", "attn_cls", "attn_short", "nt_overlap",
+    "attn_generic", "attn_cls", "attn_short", "nt_overlap", "attn_bwd1",
 };
 std::atomic<long long> g_route[MEANT_ROUTE_COUNT];
 }  // namespace

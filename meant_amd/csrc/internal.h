@@ -73,3 +73,9 @@ int attn_short_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, 
                    int causal, hipStream_t stream);
 int attn_short_bwd(const bf16* qkv, const bf16* dout, const float* lse, const float* key_mask, bf16* dqkv, int64_t G, int64_t S, int H,
                    int Dh, float scale, int causal, RotTables rot, hipStream_t stream);
+// single-pass backward (attn_bwd1.hip): Dh = 64, S <= 256 or causal S <= 512; bias2 / flags / masks as prepared by attn_bf16_bwd
+bool attn_bwd1_ok(int64_t S, int Dh, int causal);
+size_t attn_bwd1_ws(int64_t G, int64_t S, int H, int Dh);
+int attn_bwd1_launch(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* bias2, const int* flags,
+                     const uint64_t* masks, bf16* dqkv, float* part, int64_t G, int64_t S, int H, float scale, int causal, RotTables rot,
+                     hipStream_t stream);

@@ -46,5 +46,19 @@ for (G, S, causal) in [(1536, 512, 1), (1536, 196, 0)]:
     tb = timeit(lambda: check(lib.meant_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), mp, dqkv.data_ptr(), G, S, H, Dh, scale, causal,
                                                  qa.data_ptr(), qb.data_ptr(), ka.data_ptr(), kb.data_ptr(), R, BF16, ws.data_ptr(), wsb, st)), iters)
     fl = 4.0 * G * H * S * S * Dh
+    # single-pass backward (attn_bwd1) against the two-pass form: time and result
+    if Dh == 64:
+        bwd = lambda: check(lib.meant_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), mp, dqkv.data_ptr(), G, S, H, Dh, scale, causal,
+                                               qa.data_ptr(), qb.data_ptr(), ka.data_ptr(), kb.data_ptr(), R, BF16, ws.data_ptr(), wsb, st))
+        lib.meant_set_option(b"attn_bwd1", 0)
+        t2 = timeit(bwd, iters); ref = dqkv.clone().float()
+        lib.meant_set_option(b"attn_bwd1", 1)
+        dqkv.fill_(float("nan")); t1 = timeit(bwd, iters); torch.cuda.synchronize()
+        got = dqkv.float()
+        for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+            a_, r_ = got[:, sl], ref[:, sl]
+            print(f"   {name}: max|two-pass| {r_.abs().max().item():.4g}  max|diff| {(a_ - r_).abs().max().item():.4g}  rel-norm {((a_ - r_).norm() / r_.norm()).item():.3g}  nan {int(torch.isnan(a_).sum())}", flush=True)
+        print(f"   two-pass {t2:.3f} ms   single-pass {t1:.3f} ms", flush=True)
+        del ref, got
     print(f"G={G} S={S} H={H} causal={causal}: fwd {tf:.3f} ms  bwd {tb:.3f} ms   (full-square: fwd {fl/tf/1e9:.0f} TFLOP/s, bwd {2.5*fl/tb/1e9:.0f} TFLOP/s)", flush=True)
     del qkv, o, do, dqkv
