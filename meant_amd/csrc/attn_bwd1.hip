@@ -137,25 +137,49 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = a.S, H = a.H, D = H * DH;
   const int64_t ld = 3 * (int64_t)D;
-  int x_, h, g;
-  if (!attn_item(1, H, a.G, x_, h, g)) return;
-  const bf16* base = a.qkv + (int64_t)g * S * ld + h * DH;  // Q columns of this head; K at + D, V at + 2 D
-  const bf16* dO = a.dout + (int64_t)g * S * D + h * DH;
-  const bf16* Og = a.o + (int64_t)g * S * D + h * DH;
-  const float* lse = a.lse + ((int64_t)g * H + h) * S * 2;
-  bf16* dqkv = a.dqkv + (int64_t)g * S * ld + h * DH;
-  const int ntile = (S + KV_TILE - 1) / KV_TILE;
-  uint64_t sp, sk;                                           // per 64-key tile: needs the bias / tail path; dead padding
-  sload_masks(a.masks + 2 * (int64_t)g, sp, sk);
+  const int ntile = (S + KV_TILE - 1) / KV_TILE, nhalf = (S + 255) >> 8, nchunk = (S + 127) >> 7;
   const float c1 = a.scale * LOG2E;
-  const int nhalf = (S + 255) >> 8, nchunk = (S + 127) >> 7;
   const unsigned troff0 = make_troff(lane).o[0][0];         // the other three: constant bit flips of this one (see tile())
   const unsigned foff0 = (unsigned)((lane & 31) * 128 + (((lane >> 5) ^ swz(lane & 31)) << 4));
   char* myreg = smem + B1_PANEL + wave * B1_REGION;        // this wave's panel region, and its patch once the panel is done with
   const unsigned prow = lds_addr(myreg) + (lane & 31) * 128 + 8 * (lane >> 5);
   const unsigned pswz = (unsigned)swz(lane & 31) << 4;
-  float* part_w = args.part ? args.part + (((int64_t)g * H + h) * 2 * 8 + wave) * 1024 : nullptr;   // uniform; + (c - 2) * 8192 + i * 256 + 4 lane
-  bool part_valid = false;
+  // A workgroup is persistent: it walks its share of the (group, head) items of its XCD (XCD x owns the contiguous item range
+  // [x * chunk, (x + 1) * chunk), see attn_item), one STAGE = one key half of one item after the other, so that everything the
+  // next stage's first phase needs is requested while the current stage is in its last chunk and its epilogues.
+  struct Stg {                                               // all wave-uniform.  Element offsets into the kernel's buffers, not pointers:
+    int64_t qo, oo, lo, bo, po;                              // a pointer that has been through this struct is a generic one to the compiler
+    uint64_t sp, sk;                                         // (flat_load / flat_store, which also count in lgkmcnt)
+    int hk; unsigned j; int valid;                           // sp / sk: per 64-key tile: needs the bias / tail path; dead padding
+  };
+  const unsigned nitem = (unsigned)H * a.G, ichunk = (nitem + 7) / 8, xcd = blockIdx.x & 7, jstep = gridDim.x >> 3;
+  auto open_item = [&](unsigned j, Stg& t) {
+    const unsigned item = xcd * ichunk + j;
+    t.j = j;
+    t.valid = j < ichunk && item < nitem;
+    if (!t.valid) return;
+    const int g = (int)(item / H), h = (int)(item % H);
+    t.qo = (int64_t)g * S * ld + h * DH;                     // q|k|v and dq|dk|dv: Q columns of this head; K at + D, V at + 2 D
+    t.oo = (int64_t)g * S * D + h * DH;                      // o and do
+    t.lo = ((int64_t)g * H + h) * S * 2;                     // (m, log2 l) pairs
+    t.bo = (int64_t)g * ntile * KV_TILE;                     // key bias
+    t.po = (((int64_t)g * H + h) * 2 * 8 + wave) * 1024;     // partial dQ blocks of this wave: + (c - 2) * 8192 + i * 256 + 4 lane
+    sload_masks(a.masks + 2 * (int64_t)g, t.sp, t.sk);
+    t.hk = nhalf - 1;
+  };
+  auto upper_dead = [&](uint64_t sk) {                       // every tile of the upper key half is dead padding
+    bool dead = nhalf == 2;
+    for (int t = 4; t < 8 && t < ntile; ++t) dead = dead && ((sk >> t) & 1);
+    return dead;
+  };
+  // the stage after t (t.valid == 0: none).  A dead upper half is not a stage: it leaves no partial dQ, and its dK / dV rows
+  // are zeroed by the lower half's stage.  (The lower half always runs: it is the one that writes dQ.)
+  auto next_stage = [&](Stg t, bool first) -> Stg {
+    if (!first && t.hk > 0) { t.hk -= 1; return t; }
+    open_item(first ? (unsigned)(blockIdx.x >> 3) : t.j + jstep, t);
+    if (t.valid && upper_dead(t.sk)) t.hk = 0;               // (the lower-half stage zeroes the dead half's dK / dV rows on its way out)
+    return t;
+  };
 #ifdef ATTN_LAB_STAMP
   unsigned long long lab_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long lab_t = lab1_now();
@@ -164,20 +188,50 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
   // request the tq-th 64-query tile of chunk c into ring slot tq: this wave's piece (rows 8 w .. 8 w + 7) of Q, dO and O, and
   // the (m, log2 l) pairs of those rows.  The lane-derived offsets are recomputed here on purpose (from a value the compiler
   // cannot see through): hoisted out of the chunk loop they would sit in registers across phase 1, which has none to spare.
-  auto issue_tile = [&](int c, int tq) {
+  auto issue_tile = [&](const Stg& P, int c, int tq) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int row0 = c * 128 + tq * 64;
     char* slot = smem + B1_RING + tq * B1_SLOT;
     const PieceOff pq = make_piece_off(ld, S, wave, ln), pd = make_piece_off(D, S, wave, ln);
-    stage_piece(base, ld, row0, S, slot, wave, pq);
-    stage_piece(dO, D, row0, S, slot + TILE_B, wave, pd);
-    stage_piece(Og, D, row0, S, slot + 2 * TILE_B, wave, pd);
+    stage_piece(a.qkv + P.qo, ld, row0, S, slot, wave, pq);
+    stage_piece(a.dout + P.oo, D, row0, S, slot + TILE_B, wave, pd);
+    stage_piece(a.o + P.oo, D, row0, S, slot + 2 * TILE_B, wave, pd);
     if (ln < 16) {
       int i = 2 * (row0 + 8 * wave) + ln;
       i = min(i, 2 * S - 1);
-      glds4(lse + i, stats + tq * 256 + 16 * wave);
+      glds4(a.lse + P.lo + i, stats + tq * 256 + 16 * wave);
     }
+  };
+  // K half of a stage: piece w of each of its (up to) four tiles
+  auto issue_K = [&](const Stg& P) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const PieceOff pk = make_piece_off(ld, S, wave, ln);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (P.hk * 256 + 64 * kt < S) stage_piece(a.qkv + P.qo + D, ld, P.hk * 256 + 64 * kt, S, smem + B1_K + kt * TILE_B, wave, pk);
+  };
+  // K / V fragments (B operands of the score products) and the key bias of a stage
+  auto load_kv = [&](const Stg& P, bf16x8 (&kf)[KS], bf16x8 (&vf)[KS], float& bkey) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int mykey = P.hk * 256 + wave * 32 + (ln & 31);
+    const bf16* kp = a.qkv + P.qo + (int64_t)min(mykey, S - 1) * ld + D + 8 * (ln >> 5);
+    const bf16* vp = kp + D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
+    }
+    bkey = mykey < ntile * KV_TILE ? a.bias2[P.bo + mykey] : -INFINITY;   // log2 units; -inf past S; zero for every key of a PLAIN wave
+  };
+  // everything the first phase of a stage needs
+  auto request_stage = [&](const Stg& P) {
+    const int c0 = a.causal ? 2 * P.hk : 0;
+    issue_K(P);
+    issue_tile(P, c0, 0);
+    if (c0 * 128 + 64 < S) issue_tile(P, c0, 1);
   };
   // statistics of the tile in slot tq, from LDS, for the 8 rows this wave requested itself (its own vmcnt wait covers them):
   // delta = rowsum(dO o O) (8 lanes per row), -(m + log2 l)
@@ -204,10 +258,14 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     }
   };
 
-  auto half = [&](int hk, auto PLAIN_T) {
+  auto half = [&](const Stg& cur, const Stg& nxt, auto PLAIN_T) {
     constexpr bool PLAIN = decltype(PLAIN_T)::value;
+    bf16* dqkv = a.dqkv + cur.qo;
+    float* part_w = args.part + cur.po;
+    const uint64_t sk = cur.sk;
+    const int hk = cur.hk;
+    const bool part_valid = hk == 0 && nhalf == 2 && !upper_dead(sk);
     const int kh0 = hk * 256, key0 = kh0 + wave * 32, mykey = key0 + (lane & 31);
-    const int krow = min(mykey, S - 1);
     const bool wave_live = uni(key0 < S && !((sk >> (key0 >> 6)) & 1));
     unsigned deadm = 0;                                      // bit kb: keys kh0 + 32 kb .. + 31 contribute nothing (dead padding / past S)
 #pragma unroll
@@ -216,28 +274,10 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       if (k0 >= S || ((sk >> (k0 >> 6)) & 1)) deadm |= 1u << kb;
     }
     const int c0 = a.causal ? 2 * hk : 0, c1l = nchunk - 1;
-
-    // K half (piece w of each of its tiles) and the first chunk's tiles on their way before anything else
-    {
-      const PieceOff pk = make_piece_off(ld, S, wave, lane);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (kh0 + 64 * kt < S) stage_piece(base + D, ld, kh0 + 64 * kt, S, smem + B1_K + kt * TILE_B, wave, pk);
-    }
-    issue_tile(c0, 0);
-    if (c0 * 128 + 64 < S) issue_tile(c0, 1);
-    bf16x8 kf[KS], vf[KS];
-    {
-      const bf16* kp = base + (int64_t)krow * ld + D + 8 * (lane >> 5);
-      const bf16* vp = kp + D;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
-      }
-    }
-    float bkey = 0.f;                                      // key bias (log2 units; -inf past S); zero by construction when PLAIN
-    if (!PLAIN) bkey = mykey < ntile * KV_TILE ? a.bias2[(int64_t)g * ntile * KV_TILE + mykey] : -INFINITY;
+    const int c0n = a.causal ? 2 * nxt.hk : 0;               // first chunk of the next stage
+    bf16x8 kf[KS], vf[KS];                                   // K / V fragments of this wave's 32 keys (B operands of the score products)
+    float bkey;
+    load_kv(cur, kf, vf, bkey);
     f32x16 dkacc[2], dvacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -405,8 +445,8 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     };
 
     LAB1(8)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LAB1(9)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // K half, the first chunk's tiles, the fragments: requested by request_stage
+    LAB1(9)                                                  // or by the previous stage's last chunk
     // naming the fragments here makes the compiler place its own wait for their loads HERE: otherwise it cannot rule out that
     // they are still pending at the loop head and puts a vmcnt(0) in front of the first MFMA of every tile, which drains the
     // tile requested a moment before
@@ -419,7 +459,11 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     LAB1(0)
 #pragma unroll 1
     for (int c = c0; c <= c1l; ++c) {
-      const bool have_b = c * 128 + 64 < S, more = c < c1l;  // uniform
+#ifdef B1_NOTAIL
+      const bool have_b = c * 128 + 64 < S, more = c < c1l, tail = false;
+#else
+      const bool have_b = c * 128 + 64 < S, more = c < c1l, tail = !more && nxt.valid;  // uniform
+#endif
       // the slot index goes through an opaque scalar: with a literal 0 / 1 every LDS address of the tile body is loop-invariant,
       // hipcc hoists ~50 of them out of the chunk loop and spills them (and K / V fragments) across phase 1
       int slot_a = 0, slot_b = 1;
@@ -435,17 +479,27 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       }
       B1_BARRIER("vmcnt(0) lgkmcnt(0)");                     // slot 0 free; slot 1 and its statistics visible
       LAB1(2)
-      if (more) issue_tile(c + 1, 0);
+      if (more) issue_tile(cur, c + 1, 0);
+      else if (tail) issue_tile(nxt, c0n, 0);              // the next stage's first tile: slot 0 is free from here on
       // ---- phase 1, second tile (slot 1) ----
       if (have_b && wave_live && (!a.causal || c * 128 + 127 >= key0)) tile(c * 128 + 64, slot_b);
       LAB1(1)
       B1_BARRIER("lgkmcnt(0)");                              // panel complete; slot 1 free
+#ifdef B1_DBG_Y2
+      B1_BARRIER("vmcnt(0) lgkmcnt(0)");
+      __builtin_amdgcn_s_sleep(8);
+      B1_BARRIER("vmcnt(0) lgkmcnt(0)");
+#endif
       LAB1(11)
       // ---- phase 2 ----
       const int qt = wave >> 1, bh = wave & 1;
       const int q0b = c * 128 + 32 * qt;
       const bool p2 = q0b < S;                               // uniform
+#ifdef B1_DBG_NOPART
+      const bool take_part = false;
+#else
       const bool take_part = p2 && hk == 0 && part_valid && c >= 2;
+#endif
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -456,9 +510,17 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       if (take_part) {
         const float* pp = part_w + (c - 2) * 8192 + lane * 4;
 #pragma unroll
+#ifdef B1_PARTNT
+        for (int i = 0; i < 4; ++i) pv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pp + i * 256));
+#else
         for (int i = 0; i < 4; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + i * 256);
+#endif
       }
+#ifdef B1_DBG_NOROT
+      const bool rot_q = false;
+#else
       const bool rot_q = p2 && hk == 0 && a.rot.qa != nullptr;
+#endif
       {
         // loaded on every path (from the start of the q|k|v buffer when there is nothing to rotate) and named after the wait
         // below on every path: a load under one branch and its use under another would leave the compiler unable to tell that
@@ -487,45 +549,36 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
         asm volatile("" : "+v"(tr0));
         const unsigned ka0 = kaddr + (tr0 ^ (bh ? 64u : 0u)), ka1 = ka0 ^ (1024u | 32u);
         const unsigned pa0 = paddr + (tr0 ^ (b ? 64u : 0u)), pa1 = pa0 ^ (1024u | 32u);
-        // key blocks in ascending order, the reads of the next live block issued before the products of the current one
-        struct KP { u32x2 alo[2], ahi[2], blo[2], bhi[2]; };
-        auto issue = [&](int kb, KP& r) {                    // rows 32 (kb & 1).. of K tile kb >> 1 = byte kb * 4096; panel region kb
-          const unsigned ka = ka0 + kb * 4096, kc = ka1 + kb * 4096, pa = pa0 + kb * B1_REGION, pc = pa1 + kb * B1_REGION;
-          r.alo[0] = lds_read_tr16<0>(ka);
-          r.ahi[0] = lds_read_tr16<0>(kc);
-          r.blo[0] = lds_read_tr16<0>(pa);
-          r.bhi[0] = lds_read_tr16<0>(pc);
-          r.alo[1] = lds_read_tr16<16 * 128>(ka);
-          r.ahi[1] = lds_read_tr16<16 * 128>(kc);
-          r.blo[1] = lds_read_tr16<16 * 128>(pa);
-          r.bhi[1] = lds_read_tr16<16 * 128>(pc);
-        };
-        auto mma = [&](auto YOUNGER, KP& r) {
-          constexpr int younger = decltype(YOUNGER)::value;
-          asm volatile("s_waitcnt lgkmcnt(%8)"
-                       : "+v"(r.alo[0]), "+v"(r.ahi[0]), "+v"(r.blo[0]), "+v"(r.bhi[0]), "+v"(r.alo[1]), "+v"(r.ahi[1]), "+v"(r.blo[1]), "+v"(r.bhi[1])
-                       : "n"(younger));
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(r.alo[0], r.ahi[0]), pack_tr(r.blo[0], r.bhi[0]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_tr(r.alo[1], r.ahi[1]), pack_tr(r.blo[1], r.bhi[1]), acc, 0, 0, 0);
-        };
-        const std::integral_constant<int, 8> NEXT{};
-        const std::integral_constant<int, 0> LAST{};
+        // One asm statement per live key block: its eight transposed reads into FIXED registers, the wait, the two products.
+        // Reads and wait must not be separate statements: a value the compiler can see between them it may copy (to form the
+        // MFMA's register tuple, or at a loop edge), and a copy made before the read has landed carries the old content --
+        // measured: one 32 x 32 block of dQ in ~3 M wrong, now and then, when this loop kept two blocks' reads in flight.
         unsigned m = livem;
-        if (m) {
-          KP ra, rb;
-          issue(__builtin_ctz(m), ra);
+        while (m) {
+          const int kb = __builtin_ctz(m);
           m &= m - 1;
-          for (;;) {
-            if (!m) { mma(LAST, ra); break; }
-            issue(__builtin_ctz(m), rb);
-            m &= m - 1;
-            mma(NEXT, ra);
-            if (!m) { mma(LAST, rb); break; }
-            issue(__builtin_ctz(m), ra);
-            m &= m - 1;
-            mma(NEXT, rb);
-          }
+          // rows 32 (kb & 1).. of K tile kb >> 1 = byte kb * 4096 of the K image; panel region kb
+          const unsigned ka = ka0 + kb * 4096, kc = ka1 + kb * 4096, pa = pa0 + kb * B1_REGION, pc = pa1 + kb * B1_REGION;
+          asm volatile(
+              "ds_read_b64_tr_b16 v[240:241], %1\n\t"
+              "ds_read_b64_tr_b16 v[242:243], %2\n\t"
+              "ds_read_b64_tr_b16 v[244:245], %3\n\t"
+              "ds_read_b64_tr_b16 v[246:247], %4\n\t"
+              "ds_read_b64_tr_b16 v[248:249], %1 offset:2048\n\t"
+              "ds_read_b64_tr_b16 v[250:251], %2 offset:2048\n\t"
+              "ds_read_b64_tr_b16 v[252:253], %3 offset:2048\n\t"
+              "ds_read_b64_tr_b16 v[254:255], %4 offset:2048\n\t"
+              "s_waitcnt lgkmcnt(4)\n\t"
+              "v_mfma_f32_32x32x16_bf16 %0, v[240:243], v[244:247], %0\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "v_mfma_f32_32x32x16_bf16 %0, v[248:251], v[252:255], %0"
+              : "+v"(acc)
+              : "v"(ka), "v"(kc), "v"(pa), "v"(pc)
+              : "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
         }
+        // the compiler does not know that `acc` comes out of the matrix pipe: the wait states an MFMA result needs before a
+        // vector instruction may read it (18 for this shape) are spelled out here
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
       }
       LAB1(3)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile (c + 1, 0), requested a phase ago; the partial block; the rotary rows
@@ -551,12 +604,31 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       }
       if (more) {
         stat_step(0);
-        if ((c + 1) * 128 + 64 < S) issue_tile(c + 1, 1);
+        if ((c + 1) * 128 + 64 < S) issue_tile(cur, c + 1, 1);
+      } else if (tail) {                                     // phase 1 of this stage is over: slot 1 and the K / V fragment registers
+        if (c0n * 128 + 64 < S) issue_tile(nxt, c0n, 1);     // are free for the next stage
       }
       LAB1(15)
       B1_BARRIER("lgkmcnt(0)");                              // panel free; tile (c + 1, 0) and its statistics visible
       LAB1(4)
+      if (tail) issue_K(nxt);                                // nobody reads this stage's K image any more
       if (p2 && hk == 0) {
+#ifdef B1_DBG_WAIT2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef B1_DBG_LATEROT
+        if (rot_q) {
+          const float* Ar = a.rot.qa + (int64_t)qpos * a.rot.R;
+          const float* Br = a.rot.qb + (int64_t)qpos * a.rot.R;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int dh = 32 * bh + 8 * g4 + 4 * (lane >> 5);
+            const int dhc = dh < a.rot.R ? dh : 0;
+            rav[g4] = *reinterpret_cast<const f32x4*>(Ar + dhc);
+            rbv[g4] = *reinterpret_cast<const f32x4*>(Br + dhc);
+          }
+        }
+#endif
         if (rot_q) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
@@ -592,9 +664,20 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       store_transposed(dkacc, a.scale, myreg, dqkv + D, ld, key0, S, ln, 2);
     } else if (key0 < S) {                                   // dead padding: exact zeros
       const u32x4 z = {0u, 0u, 0u, 0u};
-      for (int idx = lane; idx < 32 * 16; idx += 64) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;
         const int row = idx >> 4, cc = idx & 15;
         if (key0 + row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)(key0 + row) * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
+      }
+    }
+    if (hk == 0 && upper_dead(sk)) {                         // the upper key half of this item was dead padding: exact zeros
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = 256 + wave * 32 + (idx >> 4), cc = idx & 15;
+        if (row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)row * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -602,24 +685,30 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     LAB1(6)
   };
 
+  // (every field of a stage descriptor is wave-uniform by construction; saying so keeps the address arithmetic on the scalar unit)
+  auto uni64 = [](uint64_t v) {
+    return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  auto uni_stage = [&](Stg t) {
+    t.qo = (int64_t)uni64((uint64_t)t.qo); t.oo = (int64_t)uni64((uint64_t)t.oo); t.lo = (int64_t)uni64((uint64_t)t.lo);
+    t.bo = (int64_t)uni64((uint64_t)t.bo); t.po = (int64_t)uni64((uint64_t)t.po); t.sp = uni64(t.sp); t.sk = uni64(t.sk);
+    t.hk = __builtin_amdgcn_readfirstlane(t.hk); t.j = (unsigned)__builtin_amdgcn_readfirstlane((int)t.j); t.valid = __builtin_amdgcn_readfirstlane(t.valid);
+    return t;
+  };
+  Stg cur = uni_stage(next_stage(Stg{}, true));
+  if (!cur.valid) return;
+  request_stage(cur);
 #pragma unroll 1
-  for (int hk = nhalf - 1; hk >= 0; --hk) {
-    const int key0 = hk * 256 + wave * 32;
-    bool half_dead = true;
-    for (int t = hk * 4; t < hk * 4 + 4 && t < ntile; ++t) half_dead = half_dead && ((sk >> t) & 1);
-    if (uni(half_dead && hk > 0)) {                          // nothing in the upper half is alive: zeros, and no partial dQ either (the lower
-                                                             // half always runs: it is the one that writes dQ)
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      for (int idx = lane; idx < 32 * 16; idx += 64) {
-        const int row = idx >> 4, cc = idx & 15;
-        if (key0 + row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)(key0 + row) * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
-      }
-      continue;
-    }
-    const bool wave_plain = uni(key0 + 32 <= S && !((sp >> (key0 >> 6)) & 1) && !((sk >> (key0 >> 6)) & 1));
-    if (wave_plain) half(hk, std::true_type{});
-    else half(hk, std::false_type{});
-    part_valid = hk == 1;
+  while (cur.valid) {
+    const Stg nxt = uni_stage(next_stage(cur, false));
+    const int key0 = cur.hk * 256 + wave * 32;
+    const bool wave_plain = uni(key0 + 32 <= S && !((cur.sp >> (key0 >> 6)) & 1) && !((cur.sk >> (key0 >> 6)) & 1));
+    if (wave_plain) half(cur, nxt, std::true_type{});
+    else half(cur, nxt, std::false_type{});
+    cur = nxt;
+#ifdef B1_NOTAIL
+    if (cur.valid) { B1_BARRIER("vmcnt(0) lgkmcnt(0)"); request_stage(cur); }
+#endif
   }
 #ifdef ATTN_LAB_STAMP
   if (tid == 0 && blockIdx.x < LAB1_MAX_WG)
@@ -653,7 +742,11 @@ int attn_bwd1_launch(const bf16* qkv, const bf16* o, const bf16* dout, const flo
   Bwd1Args a{{qkv, o, dout, lse, bias2, flags, dqkv, nullptr, masks, 0, (int)S, H, scale, causal, (int)G, (int)ceil_div(S, 128), rot}, part};
   MEANT_RAISE_LDS(attn_bwd1_kernel, B1_LDS);
   meant_route_hit(ROUTE_ATTN_BWD1);
-  hipLaunchKernelGGL(attn_bwd1_kernel, dim3(attn_grid(1, H, G)), dim3(512), B1_LDS, stream, a);
+  // persistent: one workgroup per CU (it takes 146 KiB of LDS) walking its XCD's share of the items; never more workgroups than items
+  int ncu = meant_num_cus() & ~7;
+  if (ncu < 8) ncu = 8;
+  const unsigned full = attn_grid(1, H, G);
+  hipLaunchKernelGGL(attn_bwd1_kernel, dim3(full < (unsigned)ncu ? full : (unsigned)ncu), dim3(512), B1_LDS, stream, a);
   MEANT_LAUNCH_CHECK("attn_bwd1");
   return MEANT_OK;
 }

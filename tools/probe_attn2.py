@@ -58,6 +58,33 @@ for (G, S, causal) in [(1536, 512, 1), (1536, 196, 0)]:
         for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
             a_, r_ = got[:, sl], ref[:, sl]
             print(f"   {name}: max|two-pass| {r_.abs().max().item():.4g}  max|diff| {(a_ - r_).abs().max().item():.4g}  rel-norm {((a_ - r_).norm() / r_.norm()).item():.3g}  nan {int(torch.isnan(a_).sum())}", flush=True)
+        if os.environ.get("PROBE_REPEAT"):                     # run-to-run determinism of the single-pass kernel (no atomics: must be bit-identical)
+            first = dqkv.clone()
+            for rep in range(int(os.environ["PROBE_REPEAT"])):
+                dqkv.fill_(float("nan")); bwd(); torch.cuda.synchronize()
+                ne = (dqkv != first) | torch.isnan(dqkv)
+                if ne.any():
+                    idx = ne.nonzero()
+                    if os.environ.get("PROBE_DUMP") and not os.path.exists(os.environ["PROBE_DUMP"]):
+                        r0 = int(idx[0, 0]); c0 = (int(idx[0, 1]) // Dh) * Dh
+                        r0 = (r0 // 32) * 32
+                        np.savez(os.environ["PROBE_DUMP"], right=first[r0:r0 + 32, c0:c0 + Dh].float().cpu().numpy(), wrong=dqkv[r0:r0 + 32, c0:c0 + Dh].float().cpu().numpy(),
+                                 r0=r0, c0=c0, S=S, qa=qa.cpu().numpy(), qb=qb.cpu().numpy(), scale=scale,
+                                 qkv=qkv[(r0 // S) * S:(r0 // S + 1) * S].float().cpu().numpy(), do=do[(r0 // S) * S:(r0 // S + 1) * S].float().cpu().numpy(),
+                                 o=o[(r0 // S) * S:(r0 // S + 1) * S].float().cpu().numpy(), lse=lse[r0 // S].cpu().numpy(),
+                                 mask=(mask[r0 // S].cpu().numpy() if mask is not None else np.ones(S, dtype=np.float32)), H=H, Dh=Dh)
+                    rows = idx[:, 0]; cols = idx[:, 1]
+                    print(f"      rep {rep}: {int(ne.sum())} elements differ; rows (g, s) {sorted(set((int(r) // S, int(r) % S) for r in rows[:2000].tolist()))[:12]} cols {sorted(set((int(c) // D, (int(c) % D) // Dh) for c in cols[:2000].tolist()))[:12]}", flush=True)
+                else:
+                    print(f"      rep {rep}: identical", flush=True)
+        if os.environ.get("PROBE_DETAIL"):
+            e = (got[:, :D] - ref[:, :D]).view(G, S, H, Dh)
+            r = ref[:, :D].view(G, S, H, Dh)
+            for c in range((S + 127) // 128):
+                sl = slice(c * 128, min(S, c * 128 + 128))
+                print(f"      dq rows {c * 128:3d}..: rel-norm {(e[:, sl].norm() / r[:, sl].norm()).item():.3g}  max {e[:, sl].abs().max().item():.4g}", flush=True)
+            bad = (e.abs() > 8 * e.abs().mean()).nonzero()
+            print("      outliers:", bad.shape[0], bad[:12].tolist(), flush=True)
         print(f"   two-pass {t2:.3f} ms   single-pass {t1:.3f} ms", flush=True)
         del ref, got
     print(f"G={G} S={S} H={H} causal={causal}: fwd {tf:.3f} ms  bwd {tb:.3f} ms   (full-square: fwd {fl/tf/1e9:.0f} TFLOP/s, bwd {2.5*fl/tb/1e9:.0f} TFLOP/s)", flush=True)
