@@ -41,8 +41,9 @@ namespace {
 //          softmax over the padding and therefore need every tile.
 constexpr float DEAD_BIAS = -1e8f, LIVE_BIAS = -1e6f;
 __global__ __launch_bounds__(64) void attn_prep_mask_kernel(const float* __restrict__ km, float* __restrict__ bias2,
-                                                             int* __restrict__ flags, int S, int nt, int causal) {
+                                                             int* __restrict__ flags, int S, int nt, int causal, unsigned* __restrict__ ctr) {
   const int g = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  if (ctr && g == 0 && t == 0 && lane < 8) ctr[lane * 16] = 0u;   // the single-pass backward's per-XCD item counters
   const int key = t * KV_TILE + lane;
   float b = 0.f;
   if (key >= S) b = -INFINITY;
@@ -922,7 +923,7 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   const int nt = (int)ceil_div(S, KV_TILE);
   float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
-  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal);
+  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal, (unsigned*)nullptr);
   MEANT_LAUNCH_CHECK("attn_prep_mask");
   uint64_t* masks = nullptr;
   if (nt <= 64) {
@@ -971,7 +972,10 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
   const int nt = (int)ceil_div(S, KV_TILE);
   float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
-  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal);
+  const bool one_pass = nt <= 64 && attn_bwd1_ok(S, Dh, causal);   // S and dP computed once, dQ through LDS (attn_bwd1.hip)
+  void* ws1 = (char*)flags + ws_flag_bytes(G, S) + ws_mask_bytes(G);   // its item counters (zeroed by the mask kernel) and partial dQ blocks
+  hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal,
+                     one_pass ? (unsigned*)ws1 : (unsigned*)nullptr);
   MEANT_LAUNCH_CHECK("attn_prep_mask");
   uint64_t* masks = nullptr;
   if (nt <= 64) {
@@ -979,10 +983,7 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
     hipLaunchKernelGGL(attn_pack_flags_kernel, dim3((unsigned)G), dim3(64), 0, stream, flags, masks, nt);
     MEANT_LAUNCH_CHECK("attn_pack_flags");
   }
-  if (masks && attn_bwd1_ok(S, Dh, causal)) {          // one pass: S and dP computed once, dQ through LDS (attn_bwd1.hip)
-    float* part = attn_bwd1_ws(G, S, H, Dh) ? (float*)((char*)masks + ws_mask_bytes(G)) : nullptr;
-    return attn_bwd1_launch(qkv, o, dout, lse, bias2, flags, masks, dqkv, part, G, S, H, scale, causal, rot, stream);
-  }
+  if (one_pass) return attn_bwd1_launch(qkv, o, dout, lse, bias2, flags, masks, dqkv, ws1, G, S, H, scale, causal, rot, stream);
   BwdArgs a{qkv, o, dout, lse, bias2, flags, dqkv, (float*)ws, masks, G * (int64_t)H * S, (int)S, H, scale, causal, (int)G, (int)ceil_div(S, 128), rot};
   MEANT_RAISE_LDS(attn_bwd_dq_kernel<64>, FWD_LDS);
   MEANT_RAISE_LDS(attn_bwd_dkv_kernel<64>, BWD_DKV_LDS);

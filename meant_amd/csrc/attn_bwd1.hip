@@ -38,7 +38,8 @@ constexpr int B1_RING = 4 * TILE_B;           // two slots of one 64-query tile 
 constexpr int B1_SLOT = 3 * TILE_B;
 constexpr int B1_PANEL = 10 * TILE_B;         // dS panel: 8 wave regions of [query sub-tile 0: 32 keys x 128 B][sub-tile 1]
 constexpr int B1_STATS = 18 * TILE_B;         // [slot][0..127: (m, log2 l) pairs | 128..191: -(m + log2 l) | 192..255: -delta]
-constexpr int B1_LDS = 18 * TILE_B + 2 * 256 * 4;
+constexpr int B1_JBOX = 18 * TILE_B + 2 * 256 * 4; // two words: the next item's index, handed from wave 0 to the others
+constexpr int B1_LDS = B1_JBOX + 64;
 constexpr int B1_REGION = 8192;
 #ifndef B1_PIPE
 #define B1_PIPE 2
@@ -47,7 +48,7 @@ constexpr int B1_REGION = 8192;
 #define B1_LB 512
 #endif
 
-struct Bwd1Args { BwdArgs b; float* part; };
+struct Bwd1Args { BwdArgs b; float* part; unsigned* ctr; };   // ctr: per-XCD item counters (16 words apart), zero at launch
 #ifdef ATTN_LAB_STAMP
 // lab build only (tools/lab/stamp_bwd1.py): per-workgroup s_memtime sums of wave 0:
 // prologue | phase 1 | wait at the barrier after it | phase 2 | wait at the barrier after it | dQ epilogue | dK dV epilogue | chunks
@@ -152,33 +153,52 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     uint64_t sp, sk;                                         // (flat_load / flat_store, which also count in lgkmcnt)
     int hk; unsigned j; int valid;                           // sp / sk: per 64-key tile: needs the bias / tail path; dead padding
   };
-  const unsigned nitem = (unsigned)H * a.G, ichunk = (nitem + 7) / 8, xcd = blockIdx.x & 7, jstep = gridDim.x >> 3;
-  auto open_item = [&](unsigned j, Stg& t) {
+  // Items are handed out dynamically, per XCD: wave 0 draws the index of the item AFTER the next one from its XCD's counter while
+  // the current item is being worked on (so the atomic's round trip is never waited for), and passes the next one's to the other
+  // waves through an LDS word published by the stage-start barrier.
+  const unsigned nitem = (unsigned)H * a.G, ichunk = (nitem + 7) / 8, xcd = blockIdx.x & 7;
+  unsigned* const ctr = args.ctr + xcd * 16;
+  unsigned* const jbox = reinterpret_cast<unsigned*>(smem + B1_JBOX);   // (not volatile: a volatile access stays a flat one; the barriers' memory clobbers order these)
+  unsigned jpend = 0;                                        // wave 0, lane 0: the item index drawn ahead
+  unsigned nit = 0;                                          // items opened so far (parity selects the jbox word)
+  auto draw = [&]() { return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto open_item = [&](unsigned j) -> Stg {
+    Stg t{0, 0, 0, 0, 0, 0, 0, 0, j, 0};
     const unsigned item = xcd * ichunk + j;
-    t.j = j;
     t.valid = j < ichunk && item < nitem;
-    if (!t.valid) return;
-    const int g = (int)(item / H), h = (int)(item % H);
-    t.qo = (int64_t)g * S * ld + h * DH;                     // q|k|v and dq|dk|dv: Q columns of this head; K at + D, V at + 2 D
-    t.oo = (int64_t)g * S * D + h * DH;                      // o and do
-    t.lo = ((int64_t)g * H + h) * S * 2;                     // (m, log2 l) pairs
-    t.bo = (int64_t)g * ntile * KV_TILE;                     // key bias
-    t.po = (((int64_t)g * H + h) * 2 * 8 + wave) * 1024;     // partial dQ blocks of this wave: + (c - 2) * 8192 + i * 256 + 4 lane
-    sload_masks(a.masks + 2 * (int64_t)g, t.sp, t.sk);
-    t.hk = nhalf - 1;
+    if (t.valid) {
+      const int g = (int)(item / H), h = (int)(item % H);
+      t.qo = (int64_t)g * S * ld + h * DH;                   // q|k|v and dq|dk|dv: Q columns of this head; K at + D, V at + 2 D
+      t.oo = (int64_t)g * S * D + h * DH;                    // o and do
+      t.lo = ((int64_t)g * H + h) * S * 2;                   // (m, log2 l) pairs
+      t.bo = (int64_t)g * ntile * KV_TILE;                   // key bias
+      t.po = (((int64_t)g * H + h) * 2 * 8 + wave) * 1024;   // partial dQ blocks of this wave: + (c - 2) * 8192 + i * 256 + 4 lane
+      sload_masks(a.masks + 2 * (int64_t)g, t.sp, t.sk);
+      t.hk = nhalf - 1;
+    }
+    return t;
   };
   auto upper_dead = [&](uint64_t sk) {                       // every tile of the upper key half is dead padding
     bool dead = nhalf == 2;
     for (int t = 4; t < 8 && t < ntile; ++t) dead = dead && ((sk >> t) & 1);
     return dead;
   };
-  // the stage after t (t.valid == 0: none).  A dead upper half is not a stage: it leaves no partial dQ, and its dK / dV rows
-  // are zeroed by the lower half's stage.  (The lower half always runs: it is the one that writes dQ.)
-  auto next_stage = [&](Stg t, bool first) -> Stg {
-    if (!first && t.hk > 0) { t.hk -= 1; return t; }
-    open_item(first ? (unsigned)(blockIdx.x >> 3) : t.j + jstep, t);
-    if (t.valid && upper_dead(t.sk)) t.hk = 0;               // (the lower-half stage zeroes the dead half's dK / dV rows on its way out)
+  // A dead upper half is not a stage: it leaves no partial dQ, and its dK / dV rows are zeroed by the lower half's stage.
+  // (The lower half always runs: it is the one that writes dQ.)
+  // (every field of a stage descriptor is wave-uniform by construction; saying so keeps the address arithmetic on the scalar unit)
+  auto uni64 = [](uint64_t v) {
+    return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  auto uni_stage = [&](Stg t) {
+    t.qo = (int64_t)uni64((uint64_t)t.qo); t.oo = (int64_t)uni64((uint64_t)t.oo); t.lo = (int64_t)uni64((uint64_t)t.lo);
+    t.bo = (int64_t)uni64((uint64_t)t.bo); t.po = (int64_t)uni64((uint64_t)t.po); t.sp = uni64(t.sp); t.sk = uni64(t.sk);
+    t.hk = __builtin_amdgcn_readfirstlane(t.hk); t.j = (unsigned)__builtin_amdgcn_readfirstlane((int)t.j); t.valid = __builtin_amdgcn_readfirstlane(t.valid);
     return t;
+  };
+  auto open_next = [&](unsigned j) -> Stg {
+    Stg t = open_item(j);
+    if (t.valid && upper_dead(t.sk)) t.hk = 0;               // (the lower-half stage zeroes the dead half's dK / dV rows on its way out)
+    return uni_stage(t);
   };
 #ifdef ATTN_LAB_STAMP
   unsigned long long lab_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     }
   };
 
-  auto half = [&](const Stg& cur, const Stg& nxt, auto PLAIN_T) {
+  auto half = [&](const Stg& cur, Stg& nxt, auto PLAIN_T) {
     constexpr bool PLAIN = decltype(PLAIN_T)::value;
     bf16* dqkv = a.dqkv + cur.qo;
     float* part_w = args.part + cur.po;
@@ -274,7 +294,6 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       if (k0 >= S || ((sk >> (k0 >> 6)) & 1)) deadm |= 1u << kb;
     }
     const int c0 = a.causal ? 2 * hk : 0, c1l = nchunk - 1;
-    const int c0n = a.causal ? 2 * nxt.hk : 0;               // first chunk of the next stage
     bf16x8 kf[KS], vf[KS];                                   // K / V fragments of this wave's 32 keys (B operands of the score products)
     float bkey;
     load_kv(cur, kf, vf, bkey);
@@ -455,7 +474,18 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     asm volatile("" : "+v"(bkey));
     stat_step(0);
     LAB1(10)
-    B1_BARRIER("lgkmcnt(0)");                                // K half, tile (c0, 0) and its statistics: in LDS
+    if (hk == 0 && wave == 0 && lane == 0) jbox[(nit + 1) & 1] = jpend;   // the item after this one (drawn while the previous one ran)
+    B1_BARRIER("lgkmcnt(0)");                                // K half, tile (c0, 0) and its statistics: in LDS; the next item's index
+    // the stage after this one (nxt.valid == 0: none): the other key half of the same item, or the first live half of the next item
+    nxt = cur;
+    if (hk > 0) nxt.hk = hk - 1;
+    else {
+      const unsigned jn = (unsigned)__builtin_amdgcn_readfirstlane((int)jbox[(nit + 1) & 1]);
+      nit += 1;
+      if (wave == 0 && lane == 0) jpend = draw();
+      nxt = open_next(jn);
+    }
+    const int c0n = a.causal ? 2 * nxt.hk : 0;               // first chunk of the next stage
     LAB1(0)
 #pragma unroll 1
     for (int c = c0; c <= c1l; ++c) {
@@ -685,30 +715,22 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     LAB1(6)
   };
 
-  // (every field of a stage descriptor is wave-uniform by construction; saying so keeps the address arithmetic on the scalar unit)
-  auto uni64 = [](uint64_t v) {
-    return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-  };
-  auto uni_stage = [&](Stg t) {
-    t.qo = (int64_t)uni64((uint64_t)t.qo); t.oo = (int64_t)uni64((uint64_t)t.oo); t.lo = (int64_t)uni64((uint64_t)t.lo);
-    t.bo = (int64_t)uni64((uint64_t)t.bo); t.po = (int64_t)uni64((uint64_t)t.po); t.sp = uni64(t.sp); t.sk = uni64(t.sk);
-    t.hk = __builtin_amdgcn_readfirstlane(t.hk); t.j = (unsigned)__builtin_amdgcn_readfirstlane((int)t.j); t.valid = __builtin_amdgcn_readfirstlane(t.valid);
-    return t;
-  };
-  Stg cur = uni_stage(next_stage(Stg{}, true));
+  if (wave == 0 && lane == 0) {
+    jbox[0] = draw();
+    jpend = draw();
+  }
+  B1_BARRIER("vmcnt(0) lgkmcnt(0)");
+  Stg cur = open_next((unsigned)__builtin_amdgcn_readfirstlane((int)jbox[0]));
   if (!cur.valid) return;
   request_stage(cur);
 #pragma unroll 1
   while (cur.valid) {
-    const Stg nxt = uni_stage(next_stage(cur, false));
+    Stg nxt = cur;
     const int key0 = cur.hk * 256 + wave * 32;
     const bool wave_plain = uni(key0 + 32 <= S && !((cur.sp >> (key0 >> 6)) & 1) && !((cur.sk >> (key0 >> 6)) & 1));
     if (wave_plain) half(cur, nxt, std::true_type{});
     else half(cur, nxt, std::false_type{});
     cur = nxt;
-#ifdef B1_NOTAIL
-    if (cur.valid) { B1_BARRIER("vmcnt(0) lgkmcnt(0)"); request_stage(cur); }
-#endif
   }
 #ifdef ATTN_LAB_STAMP
   if (tid == 0 && blockIdx.x < LAB1_MAX_WG)
@@ -724,22 +746,25 @@ extern "C" int meant_lab_stamps1(void* dst, size_t bytes) {
 }
 #endif
 
+// workspace: [item counters: 8 x 16 words | partial dQ blocks of the upper key half (256 < S <= 512 only)]
 size_t attn_bwd1_ws(int64_t G, int64_t S, int H, int Dh) {
-  if (Dh != DH || S <= 256 || S > 512) return 0;
-  return align256_((size_t)G * H * 2 * 8 * 1024 * sizeof(float));
+  if (Dh != DH || S > 512) return 0;
+  return 512 + (S > 256 ? align256_((size_t)G * H * 2 * 8 * 1024 * sizeof(float)) : 0);
 }
 
 bool attn_bwd1_ok(int64_t S, int Dh, int causal) {
   return meant_opt(MEANT_OPT_ATTN_BWD1) != 0 && Dh == DH && S > 0 && (S <= 256 || (causal && S <= 512));
 }
 
-// masks: the packed tile masks of attn_pack_flags_kernel (always present here: S <= 512 is at most 8 tiles); part: attn_bwd1_ws bytes
+// masks: the packed tile masks of attn_pack_flags_kernel (always present here: S <= 512 is at most 8 tiles); ws1: attn_bwd1_ws bytes
 int attn_bwd1_launch(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* bias2, const int* flags,
-                     const uint64_t* masks, bf16* dqkv, float* part, int64_t G, int64_t S, int H, float scale, int causal, RotTables rot,
+                     const uint64_t* masks, bf16* dqkv, void* ws1, int64_t G, int64_t S, int H, float scale, int causal, RotTables rot,
                      hipStream_t stream) {
   MEANT_REQUIRE(masks != nullptr, MEANT_ERR_ARG, "attn_bwd1: packed tile masks missing");
-  MEANT_REQUIRE(S <= 256 || part != nullptr, MEANT_ERR_WORKSPACE, "attn_bwd1: partial-dQ scratch missing");
-  Bwd1Args a{{qkv, o, dout, lse, bias2, flags, dqkv, nullptr, masks, 0, (int)S, H, scale, causal, (int)G, (int)ceil_div(S, 128), rot}, part};
+  MEANT_REQUIRE(ws1 != nullptr, MEANT_ERR_WORKSPACE, "attn_bwd1: workspace missing");
+  unsigned* ctr = (unsigned*)ws1;                            // zeroed by attn_prep_mask_kernel, which attn_bf16_bwd launches first
+  float* part = S > 256 ? (float*)((char*)ws1 + 512) : nullptr;
+  Bwd1Args a{{qkv, o, dout, lse, bias2, flags, dqkv, nullptr, masks, 0, (int)S, H, scale, causal, (int)G, (int)ceil_div(S, 128), rot}, part, ctr};
   MEANT_RAISE_LDS(attn_bwd1_kernel, B1_LDS);
   meant_route_hit(ROUTE_ATTN_BWD1);
   // persistent: one workgroup per CU (it takes 146 KiB of LDS) walking its XCD's share of the items; never more workgroups than items

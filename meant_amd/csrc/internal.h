@@ -77,5 +77,5 @@ int attn_short_bwd(const bf16* qkv, const bf16* dout, const float* lse, const fl
 bool attn_bwd1_ok(int64_t S, int Dh, int causal);
 size_t attn_bwd1_ws(int64_t G, int64_t S, int H, int Dh);
 int attn_bwd1_launch(const bf16* qkv, const bf16* o, const bf16* dout, const float* lse, const float* bias2, const int* flags,
-                     const uint64_t* masks, bf16* dqkv, float* part, int64_t G, int64_t S, int H, float scale, int causal, RotTables rot,
+                     const uint64_t* masks, bf16* dqkv, void* ws1, int64_t G, int64_t S, int H, float scale, int causal, RotTables rot,
                      hipStream_t stream);
