@@ -47,6 +47,9 @@ constexpr int B1_REGION = 8192;
 #ifndef B1_LB
 #define B1_LB 512
 #endif
+#ifndef B1_PAIR
+#define B1_PAIR 1
+#endif
 
 struct Bwd1Args { BwdArgs b; float* part; unsigned* ctr; };   // ctr: per-XCD item counters (16 words apart), zero at launch
 #ifdef ATTN_LAB_STAMP
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     const int off = r * 128 + (((ln & 7) ^ swz(r)) << 4);
     const bf16x8 dv = *reinterpret_cast<const bf16x8*>(slot + TILE_B + off);
     const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slot + 2 * TILE_B + off);
+    const float2 ml = *reinterpret_cast<const float2*>(st + 2 * r);      // (every lane of the row: one LDS round trip, not two)
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) d += (float)dv[j] * (float)ov[j];
@@ -272,7 +276,6 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xf, 0xf, true));
     d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xf, 0xf, true));
     if ((ln & 7) == 0) {
-      const float2 ml = *reinterpret_cast<const float2*>(st + 2 * r);
       st[128 + r] = -(ml.x + ml.y);
       st[192 + r] = -d;
     }
@@ -583,32 +586,71 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
         // Reads and wait must not be separate statements: a value the compiler can see between them it may copy (to form the
         // MFMA's register tuple, or at a loop edge), and a copy made before the read has landed carries the old content --
         // measured: one 32 x 32 block of dQ in ~3 M wrong, now and then, when this loop kept two blocks' reads in flight.
+        // Two key blocks per statement where there are two left (sixteen reads in flight, the second block's landing under the
+        // first one's products), one for an odd last one.
         unsigned m = livem;
         while (m) {
           const int kb = __builtin_ctz(m);
           m &= m - 1;
           // rows 32 (kb & 1).. of K tile kb >> 1 = byte kb * 4096 of the K image; panel region kb
           const unsigned ka = ka0 + kb * 4096, kc = ka1 + kb * 4096, pa = pa0 + kb * B1_REGION, pc = pa1 + kb * B1_REGION;
-          asm volatile(
-              "ds_read_b64_tr_b16 v[240:241], %1\n\t"
-              "ds_read_b64_tr_b16 v[242:243], %2\n\t"
-              "ds_read_b64_tr_b16 v[244:245], %3\n\t"
-              "ds_read_b64_tr_b16 v[246:247], %4\n\t"
-              "ds_read_b64_tr_b16 v[248:249], %1 offset:2048\n\t"
-              "ds_read_b64_tr_b16 v[250:251], %2 offset:2048\n\t"
-              "ds_read_b64_tr_b16 v[252:253], %3 offset:2048\n\t"
-              "ds_read_b64_tr_b16 v[254:255], %4 offset:2048\n\t"
-              "s_waitcnt lgkmcnt(4)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %0, v[240:243], v[244:247], %0\n\t"
-              "s_waitcnt lgkmcnt(0)\n\t"
-              "v_mfma_f32_32x32x16_bf16 %0, v[248:251], v[252:255], %0"
-              : "+v"(acc)
-              : "v"(ka), "v"(kc), "v"(pa), "v"(pc)
-              : "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+          if (B1_PAIR && m) {
+            const int kb2 = __builtin_ctz(m);
+            m &= m - 1;
+            const unsigned ka2 = ka0 + kb2 * 4096, kc2 = ka1 + kb2 * 4096, pa2 = pa0 + kb2 * B1_REGION, pc2 = pa1 + kb2 * B1_REGION;
+            asm volatile(
+                "ds_read_b64_tr_b16 v[240:241], %1\n\t"
+                "ds_read_b64_tr_b16 v[242:243], %2\n\t"
+                "ds_read_b64_tr_b16 v[244:245], %3\n\t"
+                "ds_read_b64_tr_b16 v[246:247], %4\n\t"
+                "ds_read_b64_tr_b16 v[248:249], %1 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[250:251], %2 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[252:253], %3 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[254:255], %4 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[224:225], %5\n\t"
+                "ds_read_b64_tr_b16 v[226:227], %6\n\t"
+                "ds_read_b64_tr_b16 v[228:229], %7\n\t"
+                "ds_read_b64_tr_b16 v[230:231], %8\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"          // (never more than 12 in flight: the counter has 4 bits)
+                "v_mfma_f32_32x32x16_bf16 %0, v[240:243], v[244:247], %0\n\t"
+                "ds_read_b64_tr_b16 v[232:233], %5 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[234:235], %6 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[236:237], %7 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[238:239], %8 offset:2048\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, v[248:251], v[252:255], %0\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, v[224:227], v[228:231], %0\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, v[232:235], v[236:239], %0\n\t"
+                "s_nop 15"
+                : "+v"(acc)
+                : "v"(ka), "v"(kc), "v"(pa), "v"(pc), "v"(ka2), "v"(kc2), "v"(pa2), "v"(pc2)
+                : "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+                  "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+          } else {
+            asm volatile(
+                "ds_read_b64_tr_b16 v[240:241], %1\n\t"
+                "ds_read_b64_tr_b16 v[242:243], %2\n\t"
+                "ds_read_b64_tr_b16 v[244:245], %3\n\t"
+                "ds_read_b64_tr_b16 v[246:247], %4\n\t"
+                "ds_read_b64_tr_b16 v[248:249], %1 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[250:251], %2 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[252:253], %3 offset:2048\n\t"
+                "ds_read_b64_tr_b16 v[254:255], %4 offset:2048\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, v[240:243], v[244:247], %0\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, v[248:251], v[252:255], %0\n\t"
+                "s_nop 15"
+                : "+v"(acc)
+                : "v"(ka), "v"(kc), "v"(pa), "v"(pc)
+                : "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+          }
         }
-        // the compiler does not know that `acc` comes out of the matrix pipe: the wait states an MFMA result needs before a
-        // vector instruction may read it (18 for this shape) are spelled out here
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+        // (each statement ends in the wait states an MFMA result needs before a vector instruction may read it: the compiler does
+        // not know that `acc` comes out of the matrix pipe, and a register copy it places right behind a statement -- it did, once the
+        // loop had two statements to merge -- would read rows the pipe has not written yet)
       }
       LAB1(3)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile (c + 1, 0), requested a phase ago; the partial block; the rotary rows
