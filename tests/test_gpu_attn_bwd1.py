@@ -154,3 +154,20 @@ def test_single_pass_is_bit_reproducible(dev, G, S, H, causal, mask_kind):
         else:
             ne = (d != first)
             assert not ne.any(), f"run {rep}: {int(ne.sum())} elements differ from the first run"
+
+
+@pytest.mark.parametrize("G,S,H,causal,mask_kind", [(96, 512, 4, 1, "suffix"), (96, 196, 4, 0, "none")])
+def test_forward_and_two_pass_backward_are_bit_reproducible(dev, G, S, H, causal, mask_kind):
+    """the same 24-run check on the flash forward and on the dQ + dK/dV pair (their LDS reads are separate asm statements with the
+    wait behind them: the pattern that bit the single-pass kernel's dQ product; tools/isa_inflight_check.py looks for it statically)"""
+    case = _case(G, S, H, causal, mask_kind, True, 99, dev)
+    first = None
+    for rep in range(24):
+        o, d, routes = _run(*case, G, S, H, causal, False)
+        assert routes == (0, 1)
+        if first is None:
+            first = (o.clone(), d.clone())
+        else:
+            assert not (o != first[0]).any(), f"run {rep}: forward output differs"
+            ne = (d != first[1])
+            assert not ne.any(), f"run {rep}: {int(ne.sum())} gradient elements differ from the first run"

@@ -42,3 +42,43 @@ def test_tile_draw_registers_stay_untouched_in_flight():
     for kernel, req, reg, n, bad in res:
         assert bad is None, f"{kernel}: `{req}`: v{reg} touched while in flight by `{bad}`"
         assert n > 100, f"{kernel}: `{req}` is no longer issued ahead of the K-step body ({n} instructions)"
+
+
+# ---- attention kernels: LDS reads issued by inline asm, waited for by a later asm statement ---------------------------------
+def _attn_tool():
+    spec = importlib.util.spec_from_file_location("isa_inflight_check", os.path.join(ROOT, "tools", "isa_inflight_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_attention_checker_flags_a_copy_made_before_the_wait():
+    tool = _attn_tool()
+    good = """k:
+	;;#ASMSTART
+	ds_read_b64_tr_b16 v[8:9], v2 offset:0
+	;;#ASMEND
+	v_add_u32_e32 v4, v5, v6
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_mov_b64_e32 v[20:21], v[8:9]
+"""
+    bad = good.replace("v_add_u32_e32 v4, v5, v6", "v_mov_b64_e32 v[20:21], v[8:9]")
+    assert tool.check(good) == []
+    assert [r[2] for r in tool.check(bad)] == [[8, 9]]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+@pytest.mark.parametrize("src", ["attn_bwd1.hip", "attn_bf16.hip"])
+def test_attention_kernels_do_not_touch_lds_reads_in_flight(src, tmp_path):
+    """the compiler does not know that a register written by an asm `ds_read` is still on its way: a copy it inserts between the
+    read and the wait carries the old content (that was one wrong 32 x 32 block of dQ in three million, now and then)"""
+    import subprocess
+    tool = _attn_tool()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path / "k.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-fno-slp-vectorize",
+                    os.path.join(ROOT, "meant_amd", "csrc", src), "-o", str(out)], check=True, cwd=os.path.join(ROOT, "meant_amd", "csrc"))
+    res = tool.check(out.read_text())
+    assert res == [], res[:5]
