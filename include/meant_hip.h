@@ -74,12 +74,15 @@ int meant_num_cus(void);
  *   "attn_short"       1|0   sequences of <= 16 tokens run on the one-wave-per-(group, head) kernels / on the tiled ones
  *   "nt_split"         0|1   streaming GEMM: all operand DMA issued by waves 0-3 at the top of a K-step / B tiles by waves 0-3 at
  *                            the top, A tiles by waves 4-7 after their MFMAs
+ *   "attn_bwd1"        1|0   attention backward, head dim 64, S <= 256 or causal S <= 512: one pass (scores and dP computed once,
+ *                            dS through LDS into the dQ product; persistent workgroups) / the dQ pass followed by the dK, dV pass
  */
 int meant_set_option(const char* name, int value);
 int meant_get_option(const char* name, int* value);
 /* how many launches took a given kernel route since the last reset ("nt128", "nt256", "nt256s", "nt256s_rot",
  * "nt_split", "nt_overlap", "tn128", "tn256", "tn256_det", "tn_tail", "gemm_f32", "attn_fwd", "attn_fwd_d128",
- * "attn_fwd_d96", "attn_bwd", "attn_bwd_d128", "attn_bwd_d96", "attn_generic", "attn_cls", "attn_short");
+ * "attn_fwd_d96", "attn_bwd" (the two-pass form), "attn_bwd1" (the single-pass form), "attn_bwd_d128", "attn_bwd_d96",
+ * "attn_generic", "attn_cls", "attn_short");
  * -1 for an unknown name.  Tests use it to prove that a shape reaches the kernel it is meant to exercise. */
 int64_t meant_route_count(const char* route);
 void meant_route_reset(void);
