@@ -150,7 +150,9 @@ class GemmTimer:
         proxy.meant_attn_fwd = wrap("meant_attn_fwd", lambda a: 4.0 * a[4] * a[6] * a[5] * a[5] * a[7], None, "attn_fwd",
                                     lambda a: 4.0 * a[4] * a[5] * a[6] * a[7] * es)
         # meant_attn_bwd(qkv, o, do, lse, km, dqkv, G, S, H, Dh, ...)
-        proxy.meant_attn_bwd = wrap("meant_attn_bwd", lambda a: 10.0 * a[6] * a[8] * a[7] * a[7] * a[9], None, "attn_bwd (dq + dkv)",
+        # (the whole call: one single-pass kernel at the step's shapes (csrc/attn_bwd1.hip), the dQ + dK/dV pair otherwise; FLOPs are the
+        # full-square 5-product count of SURVEY 8d either way; bytes: 9 token tensors as SURVEY 8d prices it)
+        proxy.meant_attn_bwd = wrap("meant_attn_bwd", lambda a: 10.0 * a[6] * a[8] * a[7] * a[7] * a[9], None, "attn_bwd",
                                     lambda a: 9.0 * a[6] * a[7] * a[8] * a[9] * es)
         # meant_rmsnorm_fwd(x, scale, y, rinv, rows, d, ...): read x, write y
         proxy.meant_rmsnorm_fwd = wrap("meant_rmsnorm_fwd", None, None, "rmsnorm_fwd", lambda a: 2.0 * a[4] * a[5] * es)
@@ -189,10 +191,10 @@ class GemmTimer:
 
     @staticmethod
     def pmc_ratios():
-        """measured HBM bytes (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes: profiles/r03_hbm_traffic_norm_attention.json,
+        """measured HBM bytes (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes: profiles/r03_b_hbm_traffic_norm_attention.json,
         produced by tools/pmc_step_kernels.py + tools/parse_pmc_kernels.py) over the algorithmic bytes that `others` prices each
         kernel at, per kind and shape.  A lookup in tracked counter files, like `traffic` -- None when they are missing."""
-        path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_norm_attention.json")
+        path = os.path.join(ROOT, "profiles", "r03_b_hbm_traffic_norm_attention.json")
         if not os.path.exists(path):
             return None
         k = json.load(open(path))["kernels"]
@@ -211,12 +213,15 @@ class GemmTimer:
                 u = units(sub, tag, lo, hi)
                 if u is not None:
                     ent[kind] = round(u / alg, 3)
+            one = units("attn_bwd1", tag, 7.0, 14.0)
+            if one:                                          # the single-pass backward: q|k|v, dO, O read once, dq|dk|dv written = 8 token tensors
+                ent["attn_bwd (single pass)"] = round(one / 8.0, 3)
             dq, dkv = units("attn_bwd_dq", tag, 5.0, 9.0), units("attn_bwd_dkv", tag, 5.0, 9.0)
             if dq and dkv:
-                ent["attn_bwd (dq + dkv)"] = round((dq + dkv) / 9.0, 3)
-                ent["attn_bwd vs the two-pass minimum of 12"] = round((dq + dkv) / 12.0, 3)
+                ent["attn_bwd (dq + dkv, option attn_bwd1 = 0)"] = round((dq + dkv) / 9.0, 3)
+                ent["attn_bwd two-pass vs its minimum of 12"] = round((dq + dkv) / 12.0, 3)
             out[tag] = ent
-        return {"measured_over_algorithmic_hbm_bytes": out, "source": "profiles/r03_hbm_traffic_norm_attention.json"}
+        return {"measured_over_algorithmic_hbm_bytes": out, "source": "profiles/r03_b_hbm_traffic_norm_attention.json"}
 
     def summary(self, recs=None):
         tot_t, tot_f, n = 0.0, 0.0, 0

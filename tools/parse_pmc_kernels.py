@@ -11,7 +11,7 @@ D = 768
 ALG = {
     "rmsnorm_fwd_packed": 2.0, "rmsnorm_stats": 1.0,
     "rmsnorm_fwd_pooled<POOL=2>": 2.0, "rmsnorm_fwd_pooled<POOL=2,stats>": 1.0, "rmsnorm_fwd_pooled<gelu_in>": 1.0,
-    "attn_fwd": 4.0, "attn_bwd_dq": 5.0, "attn_bwd_dkv": 6.0,
+    "attn_fwd": 4.0, "attn_bwd_dq": 5.0, "attn_bwd_dkv": 6.0, "attn_bwd1": 8.0,      # single pass: q|k|v, dO, O read once, dq|dk|dv written
 }
 
 def load(d, counter):
