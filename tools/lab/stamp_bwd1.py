@@ -39,17 +39,15 @@ for (G, S, causal) in [(1536, 512, 1), (1536, 196, 0)]:
     f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     assert f(buf.ctypes.data, buf.nbytes) == 0
     a = buf.reshape(n, 16).astype(np.float64)
-    names = ["prologue", "phase1", "wait Y", "phase2", "wait X'", "dQ epi", "dKdV epi"]
-    print(f"S={S} causal={causal}: s_memtime ticks per workgroup (wave 0), mean over {n} workgroups; chunks/wg {a[:, 7].mean():.2f}")
-    tot = a[:, :7].sum(axis=1).mean()
-    for i, nm in enumerate(names):
-        print(f"   {nm:10s} {a[:, i].mean():9.0f}  ({a[:, i].mean() / tot:5.1%})   per chunk {a[:, i].sum() / max(a[:, 7].sum(), 1):8.0f}")
-    print(f"   total      {tot:9.0f}   prologue split: set-up + requests {a[:, 8].mean():.0f}, wait for memory {a[:, 9].mean():.0f}, statistics {a[:, 10].mean():.0f}, barrier {a[:, 0].mean():.0f}")
-    tot += a[:, 8:16].sum(axis=1).mean()
-    nch = max(a[:, 7].sum(), 1)
-    print("   per chunk: wait for tile b %.0f, its statistics %.0f, barrier M %.0f, barrier Y %.0f, wait for next tile a %.0f, its statistics + request %.0f, barrier X' %.0f   (all buckets together %.0f per workgroup)"
-          % (a[:, 12].sum() / nch, a[:, 13].sum() / nch, a[:, 2].sum() / nch, a[:, 11].sum() / nch, a[:, 14].sum() / nch, a[:, 15].sum() / nch, a[:, 4].sum() / nch, tot))
-    for nc in sorted(set(a[:, 7].astype(int))):
-        sel = a[:, 7] == nc
-        print(f"   chunks={nc}: n={int(sel.sum()):6d} " + " ".join(f"{a[sel, i].mean():8.0f}" for i in range(7)))
+    # persistent workgroups: every workgroup holds the sums over all the items it drew; report per chunk (128 queries x one key half)
+    a = a[a[:, 7] > 0]
+    nch = a[:, 7].sum()
+    names = {0: "stage start: barrier", 8: "stage start: set-up + requests", 9: "stage start: wait for memory", 10: "stage start: statistics",
+             1: "phase 1 (two tiles)", 12: "wait for tile b", 13: "statistics of tile b", 2: "barrier M", 11: "barrier Y", 3: "phase 2",
+             14: "wait for the next tile a", 15: "its statistics + requests", 4: "barrier X'", 5: "dQ epilogue", 6: "dK dV epilogue (per stage)"}
+    tot = a[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15]].sum()
+    print(f"S={S} causal={causal}: {len(a)} workgroups, {int(nch)} chunks; s_memtime ticks of wave 0 per chunk, share of the total")
+    for i, nm in names.items():
+        print(f"   {nm:34s} {a[:, i].sum() / nch:8.0f}  {a[:, i].sum() / tot:6.1%}")
+    print(f"   {'total':34s} {tot / nch:8.0f}")
     del qkv, o, do, dqkv
