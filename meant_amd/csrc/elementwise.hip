@@ -82,14 +82,21 @@ __global__ __launch_bounds__(EW_THREADS) void add_rowvec_kernel(const T* __restr
     store8<T>(y + r * d + ch * 8, o);
   }
 }
+// dv[i][j] = sum over the rows r = i (mod period) of dy[r][j].  One workgroup = 64 consecutive (i, j) entries x 4 row groups (the
+// temporal embedding's gradient is 12 x 1536 entries over 1536 rows: one thread per entry left 72 workgroups walking 128 rows each)
 template <typename T>
-__global__ void add_rowvec_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dv, int64_t rows, int d, int64_t period) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= period * d) return;
-  const int64_t i = idx / d, j = idx - i * d;
+__global__ __launch_bounds__(256) void add_rowvec_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dv, int64_t rows, int d, int64_t period) {
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, g4 = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int64_t r = i; r < rows; r += period) s += to_f(dy[r * d + j]);
-  dv[idx] = s;
+  if (idx < period * d) {
+    const int64_t i = idx / d, j = idx - i * d;
+    for (int64_t r = i + g4 * period; r < rows; r += 4 * period) s += to_f(dy[r * d + j]);
+  }
+  part[g4][c] = s;
+  __syncthreads();
+  if (g4 == 0 && idx < period * d) dv[idx] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,7 +643,7 @@ extern "C" int meant_add_rowvec(const void* x, const float* v, void* y, int64_t 
 extern "C" int meant_add_rowvec_bwd(const void* dy, float* dv, int64_t rows, int64_t d, int64_t period, int dtype, void* stream) {
   EW_REQ(dy && dv && rows > 0 && d > 0 && period > 0, "add_rowvec_bwd: bad argument");
   DISPATCH_DTYPE(dtype, T,
-                 hipLaunchKernelGGL(add_rowvec_bwd_kernel<T>, dim3((unsigned)ceil_div(period * d, 256)), dim3(256), 0, (hipStream_t)stream,
+                 hipLaunchKernelGGL(add_rowvec_bwd_kernel<T>, dim3((unsigned)ceil_div(period * d, 64)), dim3(256), 0, (hipStream_t)stream,
                                     (const T*)dy, dv, rows, (int)d, period));
   MEANT_LAUNCH_CHECK("add_rowvec_bwd");
   return MEANT_OK;
