@@ -9,23 +9,29 @@
 // dK from registers as before, and dS additionally goes through LDS (written as [key][query] rows, read back by
 // ds_read_b64_tr_b16, i.e. transposed by the hardware) into the dQ product.
 //
-// One workgroup of 8 waves owns a (group, head).  The sequence's keys are worked on in halves of 256 (wave w: keys 32 w ..
-// 32 w + 31 of the half; K and V fragments and the dK / dV accumulators in registers for the whole half), its queries in
-// chunks of 128 that go HBM -> LDS by DMA.  Per chunk:
-//   phase 1  every wave: its 32 keys x the chunk's 128 queries: S, dP, P, dS, dV^T += dO^T P, dK^T += Q^T dS (the tile body of
-//            the two-pass dK/dV kernel), and dS as bf16 into the wave's own 8 KiB region of the panel [256 keys][128 queries];
-//   barrier; the next chunk's Q / dO tiles and its row statistics (m, log2 l, delta = rowsum(dO o O), computed here: there is
-//            no dQ pass that could leave them behind) are requested;
-//   phase 2  wave w: the 32 x 32 block (queries 32 (w >> 1).., head columns 32 (w & 1)..) of dQ^T = K^T dS^T over the half's
-//            256 keys: both operands by transposed reads, K from its LDS image, dS from the panel; blocks of keys that are dead
-//            padding or above the diagonal are skipped;
-//   barrier; dQ block: rotary adjoint, scale, bf16, stored through the wave's panel region.
+// One workgroup of 8 waves (one per CU) is persistent: it draws (group, head) items from its XCD's counter and works on an item in
+// STAGES of one key half (256 keys; wave w: keys 32 w .. 32 w + 31 of the half, K and V fragments and the dK / dV accumulators in
+// registers for the whole stage), a stage in CHUNKS of 128 queries, a chunk as two 64-query TILES that come HBM -> LDS by DMA:
+//   phase 1a / 1b   every wave: its 32 keys x the tile in ring slot 0, then slot 1: S, dP, P, dS, dV^T += dO^T P, dK^T += Q^T dS (the
+//                   tile body of the two-pass dK/dV kernel), and dS as bf16 into the wave's own 8 KiB region of the panel [256 keys][128
+//                   queries].  Barrier M after 1a (slot 0 is refilled behind it: next chunk's first tile), barrier Y after 1b;
+//   phase 2         wave w: the 32 x 32 block (queries 32 (w >> 1).., head columns 32 (w & 1)..) of dQ^T = K^T dS^T over the half's
+//                   live key blocks: both operands by transposed reads, K from its LDS image, dS from the panel; one asm statement per
+//                   pair of key blocks (see there why).  Then the statistics of the next tile and the request for the one after;
+//   barrier X'; dQ block: rotary adjoint (rows requested at the start of phase 2), scale, bf16, stored through the wave's panel region.
+// Every tile arrives as [Q | dO | O], each wave requesting its own 1 KiB piece of each, so that the rows' statistics (delta = rowsum(dO o
+// O), -(m + log2 l): there is no dQ pass that could leave them behind) are formed from LDS by the wave that requested those rows, behind
+// nothing but its own vmcnt wait.  Requests go out one phase before their data is needed and are waited for (vmcnt(0)) just before
+// the next ones go out: the counter is in order, a young request must never be waited for behind an old one.
 // Causal sequences longer than 256: the upper key half (which only queries >= 256 see) goes first and leaves its dQ blocks
-// as fp32 in a scratch buffer, in accumulator order, which the same wave picks up as the starting value when the lower half
-// reaches that chunk -- 64 KiB per (group, head), written and read back by the same CU within microseconds.
+// as fp32 in a scratch buffer, in accumulator order, which the same wave adds when the lower half reaches that chunk -- 64 KiB per
+// (group, head), written and read back by the same CU within microseconds.  While a stage is in its last chunk and its epilogues, the
+// next stage's K half and first two tiles are already on their way.
 // Per wave the variant of the arithmetic (PLAIN: all 32 keys live, or careful: the reference's step by step) is fixed for
-// a half, as in the two-pass kernel it was per workgroup.
-// LDS: K half 32 KiB | Q, dO chunk 32 KiB | panel 64 KiB | statistics 2 KiB = 130 KiB: one workgroup per CU, two waves per SIMD.
+// a stage, as in the two-pass kernel it was per workgroup.
+// LDS: K half 32 KiB | two ring slots of [Q | dO | O] 48 KiB | panel 64 KiB | statistics 2 KiB | item mailbox = 146 KiB: one workgroup
+// per CU, two waves per SIMD (256 registers each: the tile body is at that limit, which is why per-lane offsets pass through opaque
+// copies at their use sites -- anything the compiler can hoist out of the chunk loop it will, and spill).
 #include "attn_tiles.h"
 #include <type_traits>
 
