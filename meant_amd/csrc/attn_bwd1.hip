@@ -50,9 +50,6 @@ constexpr int B1_REGION = 8192;
 #ifndef B1_PIPE
 #define B1_PIPE 2
 #endif
-#ifndef B1_LB
-#define B1_LB 512
-#endif
 #ifndef B1_PAIR
 #define B1_PAIR 1
 #endif
@@ -142,7 +139,7 @@ __device__ __forceinline__ void stage_piece(const bf16* __restrict__ g, int64_t 
 // drain a tile requested a moment ago); the "memory" clobber keeps the compiler from moving LDS / global accesses across it
 #define B1_BARRIER(WAITS) asm volatile("s_waitcnt " WAITS "\n\ts_barrier" ::: "memory")
 
-__global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
+__global__ __launch_bounds__(512) void attn_bwd1_kernel(Bwd1Args args) {
   const BwdArgs& a = args.b;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 4;
@@ -501,11 +498,7 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
     LAB1(0)
 #pragma unroll 1
     for (int c = c0; c <= c1l; ++c) {
-#ifdef B1_NOTAIL
-      const bool have_b = c * 128 + 64 < S, more = c < c1l, tail = false;
-#else
       const bool have_b = c * 128 + 64 < S, more = c < c1l, tail = !more && nxt.valid;  // uniform
-#endif
       // the slot index goes through an opaque scalar: with a literal 0 / 1 every LDS address of the tile body is loop-invariant,
       // hipcc hoists ~50 of them out of the chunk loop and spills them (and K / V fragments) across phase 1
       int slot_a = 0, slot_b = 1;
@@ -527,21 +520,12 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       if (have_b && wave_live && (!a.causal || c * 128 + 127 >= key0)) tile(c * 128 + 64, slot_b);
       LAB1(1)
       B1_BARRIER("lgkmcnt(0)");                              // panel complete; slot 1 free
-#ifdef B1_DBG_Y2
-      B1_BARRIER("vmcnt(0) lgkmcnt(0)");
-      __builtin_amdgcn_s_sleep(8);
-      B1_BARRIER("vmcnt(0) lgkmcnt(0)");
-#endif
       LAB1(11)
       // ---- phase 2 ----
       const int qt = wave >> 1, bh = wave & 1;
       const int q0b = c * 128 + 32 * qt;
       const bool p2 = q0b < S;                               // uniform
-#ifdef B1_DBG_NOPART
-      const bool take_part = false;
-#else
       const bool take_part = p2 && hk == 0 && part_valid && c >= 2;
-#endif
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -552,17 +536,9 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       if (take_part) {
         const float* pp = part_w + (c - 2) * 8192 + lane * 4;
 #pragma unroll
-#ifdef B1_PARTNT
-        for (int i = 0; i < 4; ++i) pv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pp + i * 256));
-#else
         for (int i = 0; i < 4; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + i * 256);
-#endif
       }
-#ifdef B1_DBG_NOROT
-      const bool rot_q = false;
-#else
       const bool rot_q = p2 && hk == 0 && a.rot.qa != nullptr;
-#endif
       {
         // loaded on every path (from the start of the q|k|v buffer when there is nothing to rotate) and named after the wait
         // below on every path: a load under one branch and its use under another would leave the compiler unable to tell that
@@ -694,22 +670,6 @@ __global__ __launch_bounds__(B1_LB) void attn_bwd1_kernel(Bwd1Args args) {
       LAB1(4)
       if (tail) issue_K(nxt);                                // nobody reads this stage's K image any more
       if (p2 && hk == 0) {
-#ifdef B1_DBG_WAIT2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifdef B1_DBG_LATEROT
-        if (rot_q) {
-          const float* Ar = a.rot.qa + (int64_t)qpos * a.rot.R;
-          const float* Br = a.rot.qb + (int64_t)qpos * a.rot.R;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int dh = 32 * bh + 8 * g4 + 4 * (lane >> 5);
-            const int dhc = dh < a.rot.R ? dh : 0;
-            rav[g4] = *reinterpret_cast<const f32x4*>(Ar + dhc);
-            rbv[g4] = *reinterpret_cast<const f32x4*>(Br + dhc);
-          }
-        }
-#endif
         if (rot_q) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
