@@ -1199,6 +1199,9 @@ def patchify(images, p: int, dtype: torch.dtype, mean: float = 0.0, std: float =
     return out
 
 
+EMB_BF16_TABLE = os.environ.get("MEANT_EMB_BF16_TABLE", "1") == "1"     # 0: the bf16 tier's lookup reads the fp32 table (A/B measurements)
+
+
 class _Embedding(torch.autograd.Function):
     """nn.Embedding lookup (meant/meant.py:211) emitting the compute dtype directly."""
 
@@ -1209,9 +1212,17 @@ class _Embedding(torch.autograd.Function):
         V, d = table.shape
         n = ids_c.numel()
         out = torch.empty((*ids.shape, d), device=table.device, dtype=dtype)
-        tf = _c(table.detach().float())
-        check(lib.meant_embedding_fwd(_p(tf), _p(ids_c), _p(out), n, d, V, F32 if dtype == torch.float32 else BF16, _stream()),
-              "embedding_fwd")
+        if dtype == torch.bfloat16 and EMB_BF16_TABLE and d % 8 == 0 and V < (1 << 31):
+            # bf16 tier: rows copied from a bf16 image of the table (the weight cache's: rebuilt when the parameter changes, shared
+            # with a tied vocabulary decoder) instead of read as fp32 and rounded on the way -- same values, half the gather's reads
+            # (0.51 -> 0.37 ms at 786 k tokens of 768).  Ids are clamped into the table as meant_embedding_fwd clamps them.
+            tb = weights.get((table,), torch.bfloat16, False)
+            idx = ids_c.view(-1).clamp(0, V - 1).to(torch.int32)
+            check(lib.meant_gather_rows(_p(tb), _p(idx), None, _p(out), n, d, BF16, _stream()), "gather_rows")
+        else:
+            tf = _c(table.detach().float())
+            check(lib.meant_embedding_fwd(_p(tf), _p(ids_c), _p(out), n, d, V, F32 if dtype == torch.float32 else BF16, _stream()),
+                  "embedding_fwd")
         ctx.save_for_backward(ids_c)
         ctx.meta = (V, d)
         ctx.table = table                                # the Parameter itself: its gradient sink, if any, is looked up in backward
