@@ -261,6 +261,12 @@ class GemmTimer:
         return tot / n if n else None
 
 
+def _fold_state(E):
+    """whether the encoder layers fold encode2[0] into encode2[1]'s GEMM (meant_amd.ops.fold_wanted: by depth unless forced)"""
+    from meant_amd import ops
+    return bool(ops.FUSE_NORM_LINEAR) if ops.FUSE_NORM_LINEAR is not None else E >= ops.FOLD_AUTO_DEPTH
+
+
 def build_model(E: int, device):
     import meant_amd
     torch.manual_seed(1234)
@@ -604,7 +610,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": workload,
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "micro_batches": micro,
-                          "train_mode_dropout": not args.eval_mode, "activation_checkpointing": True if args.checkpoint else (int(args.checkpoint_layers) or False), "grad_allreduce": reducer.active,
+                          "train_mode_dropout": not args.eval_mode, "activation_checkpointing": True if args.checkpoint else (int(args.checkpoint_layers) or False),
+                          "norm_linear_fold": _fold_state(E), "grad_allreduce": reducer.active,
                           "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1),
                           "gflop_per_sample_executed": round(flops_per_sample_executed(E) / 1e9, 1)},
                "roofline": roofline}
