@@ -261,10 +261,12 @@ class GemmTimer:
         return tot / n if n else None
 
 
-def _fold_state(E):
-    """whether the encoder layers fold encode2[0] into encode2[1]'s GEMM (meant_amd.ops.fold_wanted: by depth unless forced)"""
+def _fold_state():
+    """which encoder layers folded encode2[0] into encode2[1]'s GEMM during the run (meant_amd.ops.fold_wanted: by the size of
+    the stack unless forced): False / True / "mixed" (one stack did, the other did not)"""
     from meant_amd import ops
-    return bool(ops.FUSE_NORM_LINEAR) if ops.FUSE_NORM_LINEAR is not None else E >= ops.FOLD_AUTO_DEPTH
+    sep, folded = ops.fold_calls
+    return "mixed" if sep and folded else bool(folded)
 
 
 def build_model(E: int, device):
@@ -611,7 +613,7 @@ def main():
                "config": {"workload": workload,
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "micro_batches": micro,
                           "train_mode_dropout": not args.eval_mode, "activation_checkpointing": True if args.checkpoint else (int(args.checkpoint_layers) or False),
-                          "norm_linear_fold": _fold_state(E), "grad_allreduce": reducer.active,
+                          "norm_linear_fold": _fold_state(), "grad_allreduce": reducer.active,
                           "gflop_per_sample": round(flops_per_sample(E) / 1e9, 1),
                           "gflop_per_sample_executed": round(flops_per_sample_executed(E) / 1e9, 1)},
                "roofline": roofline}

@@ -424,7 +424,7 @@ def _run_stack(encoders, x, *args, checkpoint=False):
     """all encoder layers of one stack; returns either the token tensor, or -- with POOL_LAST_LINEAR -- the
     (h, res, weight, bias) part that ops.pool_linear_cat pools.  checkpoint: bool, or the number of leading layers to recompute"""
     n = len(encoders)
-    ops.set_depth_hint(n)                                  # deep stacks fold their norms into the consumer Linears (ops.fold_wanted)
+    ops.set_stack_hint(n, x.numel() // x.shape[-1], x.shape[-1])      # big stacks fold their norms into the consumer Linears (ops.fold_wanted)
     for i, enc in enumerate(encoders):
         ck = checkpoint if isinstance(checkpoint, bool) else i < checkpoint
         last = enc.encode2[-1]
@@ -655,7 +655,7 @@ class meant_language_pretrainer(nn.Module):
     def _encode(self, words, attention_mask):
         dt = resolve_compute_dtype(self, None)
         x = _embed(self.embedding, words, dt)
-        ops.set_depth_hint(len(self.languageEncoders))
+        ops.set_stack_hint(len(self.languageEncoders), x.numel() // x.shape[-1], x.shape[-1])
         for enc in self.languageEncoders:
             x = enc(x, attention_mask=attention_mask)
         return x
@@ -707,7 +707,7 @@ class meant_vision_pretrainer(nn.Module):
     def forward(self, images):
         dt = resolve_compute_dtype(self, images)
         x = self.patchEmbed(images, dt)                                  # [B, n, d]
-        ops.set_depth_hint(len(self.visionEncoders))
+        ops.set_stack_hint(len(self.visionEncoders), x.numel() // x.shape[-1], x.shape[-1])
         for enc in self.visionEncoders:
             x = enc(x)
         b, n, c = x.shape

@@ -412,37 +412,47 @@ def linear_gelu_rmsnorm_pooled(x, weight, bias, scale, eps=1e-8, drop_p=0.0, see
 # the norm's own term d x = ... - kcoef x rides the input-gradient GEMM's epilogue, and the backward of the NEXT norm down the
 # layer (which produces the gradient of this Linear's output anyway) emits everything that term needs in the same pass
 # (meant_rmsnorm_bwd_chain).
-# AUTO by default: on for models of FOLD_AUTO_DEPTH encoder layers per stack or more, off below.  Measured on the bench step ("RMSNorm folded into the consumer Linear") the fold saves
-# 0.25 ms of forward passes and the whole RMSNorm backward of encode2[0] (0.66 ms text, 0.24 ms vision per layer), but the
-# chained norm backward that has to emit the scaled gradient, the row coefficients and the bias gradient on top of its own
-# work costs 0.63 ms more than the plain kernel (a third accumulator set per lane: 256 registers, scheduling fences) and the
-# extended GEMM epilogue 0.06 ms: the step comes out even (2963-3003 against 3013-3024 samples/s; 3050 against 3059 late in round 3).
-# What the fold always saves is MEMORY: the normalised tensor of every folded norm, one [tokens, d] activation per stack layer.
-# At 12 encoder layers (the reference CLI's default depth, in_loop_train.py:418) that is the difference between 128 samples per
-# GPU fitting in one pass (258 samples/s) and needing two micro-batches (247) or recomputation (218): hence the depth rule.
+# AUTO by default: on when one saved [tokens, d] tensor per layer of the stack in flight adds up to FOLD_AUTO_BYTES or more
+# (layers x tokens x d x 2 B: the memory the fold gives back), off below.  Measured on the bench step (DESIGN.md section 6,
+# "RMSNorm folded into the consumer Linear") the fold saves 0.25 ms of forward passes and the whole RMSNorm backward of
+# encode2[0] (0.66 ms text, 0.24 ms vision per layer), but the chained norm backward that has to emit the scaled gradient, the
+# row coefficients and the bias gradient on top of its own work costs 0.63 ms more than the plain kernel (a third accumulator
+# set per lane: 256 registers, scheduling fences) and the extended GEMM epilogue 0.06 ms: the step comes out even to 2 % behind
+# (2963-3003 against 3013-3024 samples/s; 3050 against 3059 late in round 3; the 12-layer MLM pretrainer at 64 sequences 794 k
+# against 810 k tokens/s).  What the fold always saves is MEMORY: the normalised tensor of every folded norm.  At 12 encoder
+# layers (the reference CLI's default depth, in_loop_train.py:418) and 128 samples per GPU that is the difference between the
+# step fitting in one pass (253-259 samples/s) and needing two micro-batches (247) or recomputation (218): hence the rule --
+# text stack there 12 layers x 786,432 tokens (128 x lag 12 x 512) x 768 x 2 B = 14.5 GB, vision stack 5.5 GB, both fold; the
+# same depth at 32 per GPU (3.6 / 1.4 GB), the 12-layer MLM pretrainer (0.6 GB) and the one-layer headline step (1.2 / 0.5 GB)
+# keep the separate norm.
 # MEANT_FUSE_NORM_LINEAR=1 / =0 (or ops.FUSE_NORM_LINEAR = True / False) force it on / off; the parity tests run both paths.
 _fold_env = os.environ.get("MEANT_FUSE_NORM_LINEAR")
-FUSE_NORM_LINEAR = None if _fold_env is None else (_fold_env == "1")      # None: by the depth of the model in flight
-FOLD_AUTO_DEPTH = 4
-_depth_hint = 1
+FUSE_NORM_LINEAR = None if _fold_env is None else (_fold_env == "1")      # None: by the size of the stack in flight
+FOLD_AUTO_BYTES = 4 << 30                                                 # sized for 288 GB of HBM per GPU
+_stack_bytes = 0
 
 
-def set_depth_hint(n: int) -> None:
-    """called by the model classes at the top of forward: encoder layers per stack of the model that is about to run"""
-    global _depth_hint
-    _depth_hint = int(n)
+def set_stack_hint(layers: int, tokens: int, d: int) -> None:
+    """called by the model classes before they run a stack of encoder layers: what one bf16 [tokens, d] tensor per layer adds up to"""
+    global _stack_bytes
+    _stack_bytes = int(layers) * int(tokens) * int(d) * 2
 
 
 def fold_wanted() -> bool:
-    return bool(FUSE_NORM_LINEAR) if FUSE_NORM_LINEAR is not None else _depth_hint >= FOLD_AUTO_DEPTH
+    return bool(FUSE_NORM_LINEAR) if FUSE_NORM_LINEAR is not None else _stack_bytes >= FOLD_AUTO_BYTES
+
+
+fold_calls = [0, 0]                                                       # [separate, folded] decisions taken so far (bench.py reports them)
 
 
 def norm_linear_ok(x, weight) -> bool:
     """shapes the folded path covers: bf16 tier, K a multiple of 64, a packed norm width, 16-byte aligned rows"""
     d = x.shape[-1]
     rows = x.numel() // d
-    return bool(fold_wanted() and x.dtype == torch.bfloat16 and x.is_cuda and d % 64 == 0 and weight.shape[1] == d
-                and weight.shape[0] % 8 == 0 and rows > 0 and lib.meant_rmsnorm_pooled_ok(rows, d, rows))
+    ok = bool(fold_wanted() and x.dtype == torch.bfloat16 and x.is_cuda and d % 64 == 0 and weight.shape[1] == d
+              and weight.shape[0] % 8 == 0 and rows > 0 and lib.meant_rmsnorm_pooled_ok(rows, d, rows))
+    fold_calls[ok] += 1
+    return ok
 
 
 def _scaled_weight(weight, gain):

@@ -97,6 +97,30 @@ def test_dropin_packages_resolve():
             del sys.modules[mod]
 
 
+def test_norm_linear_fold_rule(monkeypatch):
+    """the RMSNorm-into-Linear fold is decided by the size of the stack in flight unless forced (ops.fold_wanted): it is even
+    to slightly behind on time and saves one [tokens, d] tensor per layer, so only stacks where that adds up take it"""
+    from meant_amd import ops
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", None)
+    monkeypatch.setattr(ops, "_stack_bytes", 0)
+    assert not ops.fold_wanted()
+    ops.set_stack_hint(1, 128 * 12 * 512, 768)               # the headline step's text stack (lag 12)
+    assert not ops.fold_wanted()
+    ops.set_stack_hint(12, 64 * 512, 768)                    # the MLM pretrainer: deep, few tokens
+    assert not ops.fold_wanted()
+    ops.set_stack_hint(12, 32 * 12 * 512, 768)               # 12 layers at 32 samples per GPU: fits as it is
+    assert not ops.fold_wanted()
+    ops.set_stack_hint(12, 128 * 12 * 512, 768)              # 12 layers at 128 per GPU: text stack
+    assert ops.fold_wanted()
+    ops.set_stack_hint(12, 128 * 12 * 196, 768)              # ... and its vision stack
+    assert ops.fold_wanted()
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", False)      # MEANT_FUSE_NORM_LINEAR=0
+    assert not ops.fold_wanted()
+    ops.set_stack_hint(1, 64, 64)
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", True)       # MEANT_FUSE_NORM_LINEAR=1
+    assert ops.fold_wanted()
+
+
 def test_rotary_tables_match_golden(golden):
     """host-side table builder (CPU part of the rotary path) against the reference's rotated vectors"""
     import meant_amd
