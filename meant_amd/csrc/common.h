@@ -75,6 +75,10 @@ template <> struct Vec8<bf16> {
   bf16x8 v;
   __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
   __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+  __device__ __forceinline__ unsigned raw(int i) const {                 // the stored bits of element i
+    typedef __attribute__((ext_vector_type(4))) unsigned uvec4;
+    return (__builtin_bit_cast(uvec4, v)[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+  }
 };
 
 // one rotary pair (2j, 2j+1) with the products contracted the same way wherever it is evaluated (a free choice of fma by the
@@ -135,6 +139,28 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The same sums on the VALU: four DPP adds leave every lane with the sum of its row of 16, four v_readlane collect the rows.
+// __shfl_xor compiles to six DEPENDENT ds_bpermute_b32 + s_waitcnt lgkmcnt(0) pairs (~64 clocks of LDS latency each), which a
+// streaming kernel at 2-3 waves per SIMD cannot hide; EXEC must be all ones (wave-uniform control flow around the call).
+#define MEANT_DPP_ADD(v, CTRL) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xf, 0xf, true)))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = MEANT_DPP_ADD(v, 0xB1);                          // quad_perm [1,0,3,2]
+  v = MEANT_DPP_ADD(v, 0x4E);                          // quad_perm [2,3,0,1]
+  v = MEANT_DPP_ADD(v, 0x141);                         // row_half_mirror
+  v = MEANT_DPP_ADD(v, 0x140);                         // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// 1 / (||x|| / sqrt(d) + eps) from the row's sum of squares (utils/rms_norm.py:50-57), IEEE square root and division.  The
+// hardware v_sqrt_f32 / v_rcp_f32 pair (1 ulp each, ~30 instructions fewer per row) was measured on top of the DPP sums:
+// no difference in the pooled kernels (0.481 / 0.799 ms against 0.498 / 0.766 ms forward / backward, HEAD 0.647 / 0.867 on
+// both boxes), so the exact form stays
+__device__ __forceinline__ float rms_rinv(float sumsq, float inv_sqrt_d, float eps) {
+  return 1.0f / (sqrtf(sumsq) * inv_sqrt_d + eps);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // exact-erf GELU for the bf16 tier's GEMM epilogues, where libm's erff (~40 VALU instructions per element) is paid on
 // 65536 outputs per tile with the matrix pipe idle: Phi(x) through the Abramowitz-Stegun 7.1.26 rational form of erfc
@@ -161,6 +187,17 @@ __device__ __forceinline__ float gelu_phi_fast(float x) {
   p = fmaf(p, t, 0.254829592f);
   const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
   return x < 0.f ? half_erfc : 1.0f - half_erfc;
+}
+// Phi(x) of a STORED bf16 pre-activation by table (phi_table.inc, tools/gen_phi_table.py): the gelu-on-load norm kernels are
+// VALU-bound on the rational form above (a v_rcp, a v_exp and ~12 more operations per element); a bf16 x has 1664 magnitudes
+// per sign between 2^-10 and 8 and Phi is constant to bf16 rounding outside them, so Phi(x) is one clamp of the raw bits and
+// one LDS read of a 13 KiB table.  phi_slot: index of raw bf16 bits (low 16 bits of `bits`) into the table, x > 0 half first.
+constexpr unsigned PHI_LO = 0x3A80u, PHI_HI = 0x40FFu, PHI_N = PHI_HI - PHI_LO + 1;
+__device__ __forceinline__ unsigned phi_slot(unsigned bits) {
+  unsigned m = bits & 0x7FFFu;
+  m = m < PHI_LO ? PHI_LO : m;
+  m = m > PHI_HI ? PHI_HI : m;
+  return (m - PHI_LO) + ((bits >> 15) & 1u) * PHI_N;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
@@ -190,26 +227,56 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
   z = z ^ (z >> 31);
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
-// Dropout keep-multipliers for 8 consecutive elements starting at element index `base` (a multiple of 8): one
-// 64-bit hash decides 4 elements, 16 bits each (keep iff the 16-bit draw >= p * 65536), so the price per element is a
-// quarter of a splitmix round.  The multiplier is 1 / (1 - p_q) for the quantised p_q the draws really implement.
+// Dropout keep-multipliers for 8 consecutive elements starting at element index `base` (a multiple of 8): a 16-bit draw per
+// element (keep iff draw >= p * 65536); the multiplier is 1 / (1 - p_q) for the quantised p_q the draws really implement.
 // Forward and backward call this with the same (seed, base) and get the same mask.
-// When p is a multiple of 1/256 (nn.Dropout()'s default 0.5 is) 8 bits per element decide exactly the same keep probability,
-// and ONE hash serves all 8 elements: the 64-bit multiplies of a splitmix round are quarter-rate integer multiplies, a round per
-// four elements was a quarter of the VALU time of the gelu-on-load norm kernels.
+// When p is a multiple of 1/256 (nn.Dropout()'s default 0.5 is) 8 bits per element decide exactly the same keep probability:
+// two 32-bit draws serve the 8 elements (four for the 16-bit form).
+#ifndef DROP_HASH32
+#define DROP_HASH32 1
+#endif
+// 32 well-mixed bits of (seed, block, stream j): murmur3's 32-bit finaliser over the block counter xor a seed word -- two
+// quarter-rate multiplies against the ~30 of a 64-bit splitmix round (a 64 x 64 multiply is four of them, three per round)
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t blk, uint32_t j) {
+  const uint32_t hi = (uint32_t)(blk >> 32);                              // nonzero only past 2^35 elements
+  const uint32_t k = (uint32_t)blk ^ ((hi << 17) | (hi >> 15));
+  const uint32_t s = ((uint32_t)seed + 0x9E3779B9u * (j + 1)) ^ ((uint32_t)(seed >> 32) * 0x7FEB352Du);   // wave-uniform
+  return mix32(k ^ s);
+}
 __device__ __forceinline__ void keep_scale8(float p, uint64_t seed, uint64_t base, float (&m)[8]) {
   const unsigned thr = (unsigned)(p * 65536.0f);
   const float sc = 65536.0f / (float)(65536u - thr);
   if ((thr & 0xffu) == 0) {                            // wave-uniform: p comes from the kernel arguments
+    const unsigned thr8 = thr >> 8;
+#if DROP_HASH32
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t z = draw32(seed, base >> 3, (uint32_t)h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) m[4 * h + q] = ((z >> (8 * q)) & 0xffu) >= thr8 ? sc : 0.0f;
+    }
+#else
     uint64_t z = seed + ((base >> 3) | (1ull << 62)) * 0x9E3779B97F4A7C15ull;     // a counter space of its own
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
-    const unsigned thr8 = thr >> 8;
 #pragma unroll
     for (int q = 0; q < 8; ++q) m[q] = ((unsigned)(z >> (8 * q)) & 0xffu) >= thr8 ? sc : 0.0f;
+#endif
     return;
   }
+#if DROP_HASH32
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const uint32_t z = draw32(seed, base >> 3, 2u + (uint32_t)h);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m[2 * h + q] = ((z >> (16 * q)) & 0xffffu) >= thr ? sc : 0.0f;
+  }
+#else
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     uint64_t z = seed + ((base >> 2) + h) * 0x9E3779B97F4A7C15ull;
@@ -219,6 +286,7 @@ __device__ __forceinline__ void keep_scale8(float p, uint64_t seed, uint64_t bas
 #pragma unroll
     for (int q = 0; q < 4; ++q) m[4 * h + q] = ((unsigned)(z >> (16 * q)) & 0xffffu) >= thr ? sc : 0.0f;
   }
+#endif
 }
 
 // ---- LDS helpers -------------------------------------------------------------------------------

@@ -20,6 +20,19 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x);
 template <> __device__ __forceinline__ float gelu_grad_t<float>(float x) { return gelu_erf_grad(x); }
 template <> __device__ __forceinline__ float gelu_grad_t<bf16>(float x) { return gelu_erf_grad_fast(x); }
 
+// Phi(x) for every bf16 x with 2^-10 <= |x| < 8 (common.h: phi_slot); each workgroup of a gelu-on-load kernel copies it to LDS
+__device__ const float g_phi_tab[2 * PHI_N] = {
+#include "phi_table.inc"
+};
+template <typename T> constexpr bool PHI_TABLE = sizeof(T) == 2;          // bf16 tier only: an fp32 pre-activation has no small domain
+// Forward only.  In the backward (two waves per SIMD, nothing to cover the LDS latency of a 64-lane gather, ~10 clocks of bank
+// conflicts each) the table measured 10 % SLOWER than the rational form, and a mix of the two (some elements of every 8 by
+// table, the rest by arithmetic, to use both pipes) was slower than the table alone in the forward (tools/probe_norm_pooled3.py).
+__device__ __forceinline__ void phi_tab_to_lds(float* dst) {
+  for (int j = threadIdx.x; j < (int)(2 * PHI_N); j += NORM_THREADS) dst[j] = g_phi_tab[j];
+  __syncthreads();
+}
+
 
 // d_part / offset: the partial and the bias form of utils/rms_norm.py:44-57 (RMSNorm(d, p, bias=True)): the statistics are taken over
 // the first d_part = int(d p) elements of a row only (d_part == d: the full-width form the MEANT path uses), and `offset` (float [d],
@@ -224,8 +237,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_packed_kernel(const 
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) s += rsel[c] == r ? ss[c] : 0.f;
-      s = wave_sum(s);
-      const float rv = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+      s = wave_sum_dpp(s);
+      const float rv = rms_rinv(s, inv_sqrt_d, eps);
       if (lane == 0) rinv_out[row0 + r] = rv;
 #pragma unroll
       for (int c = 0; c < C; ++c) rr[c] = rsel[c] == r ? rv : rr[c];
@@ -272,8 +285,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_stats_packed_kernel(cons
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) s += rsel[c] == r ? ss[c] : 0.f;
-      s = wave_sum(s);
-      if (lane == 0) rinv_out[row0 + r] = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+      s = wave_sum_dpp(s);
+      if (lane == 0) rinv_out[row0 + r] = rms_rinv(s, inv_sqrt_d, eps);
     }
   }
 }
@@ -293,6 +306,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
                                                                            int64_t ngroups, int d, int R, float eps, float drop_p,
                                                                            uint64_t seed, float* __restrict__ pooled, int group_rows) {
   __shared__ float red[4][C * 64 * 8];                 // per wave: the column sums of its C * 64 chunks
+  __shared__ float phi_s[(GELU_IN && PHI_TABLE<T>) ? 2 * PHI_N : 1];
+  if constexpr (GELU_IN && PHI_TABLE<T>) phi_tab_to_lds(phi_s);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nchunk = d >> 3;
   const float inv_sqrt_d = rsqrtf((float)d);
@@ -327,7 +342,10 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[c].set(i, gelu_erf_fast(v[c].get(i)));
+          for (int i = 0; i < 8; ++i) {
+            if constexpr (PHI_TABLE<T>) v[c].set(i, v[c].get(i) * phi_s[phi_slot(v[c].raw(i))]);
+            else v[c].set(i, gelu_erf_fast(v[c].get(i)));
+          }
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -342,8 +360,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_pooled_kernel(const 
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) s += rsel[c] == r ? ss[c] : 0.f;
-        s = wave_sum(s);
-        const float rv = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+        s = wave_sum_dpp(s);
+        const float rv = rms_rinv(s, inv_sqrt_d, eps);
         if (lane == 0) rinv_out[row0 + r] = rv;
 #pragma unroll
         for (int c = 0; c < C; ++c) rr[c] = rsel[c] == r ? rv : rr[c];
@@ -492,12 +510,12 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) s += rsel[c] == r ? cd[c] : 0.f;
-      s = wave_sum(s);
+      s = wave_sum_dpp(s);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         if (rsel[c] == r) {
-          const float nsd = (1.0f / rr[c] - eps) * (float)d;          // ||x|| * sqrt(d)
-          kk[c] = nsd > 0.f ? s * rr[c] * rr[c] / nsd : 0.f;
+          const float nsd = (__builtin_amdgcn_rcpf(rr[c]) - eps) * (float)d;          // ||x|| * sqrt(d)
+          kk[c] = nsd > 0.f ? s * rr[c] * rr[c] * __builtin_amdgcn_rcpf(nsd) : 0.f;
         }
       }
     }
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(NORM_THREADS, 2) void rmsnorm_bwd_packed_kernel(con
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) s += rsel[c] == r ? rd[c] : 0.f;
-        s = wave_sum(s);
+        s = wave_sum_dpp(s);
         if (lane == 0) {
           const float rv1 = ch.up_rinv[row0 + r];
           const float den = (1.0f - ch.up_eps * rv1) * (float)ch.up_d;      // = ||x_up|| sqrt(d) r
