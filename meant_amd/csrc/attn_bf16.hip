@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
           }
       }
       float tmax = fmaxf(fmaxf(tmx[0], tmx[1]), fmaxf(tmx[2], tmx[3]));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      tmax = xor32_max(tmax);
       // m_run stays finite for every real query: key 0 is never above the diagonal and biases are finite for key < S
       if (!__all(tmax <= m_run)) {
         const float m_new = fmaxf(m_run, tmax);
@@ -243,9 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
           sacc[sb][e] = p;
           ps[e & 3] += p;
         }
-      float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-      psum += __shfl_xor(psum, 32, 64);
-      l_run += psum;
+      l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);      // this lane's keys only: the two halves of a query's lanes meet after the loop
       // O^T += V^T P^T
       const unsigned vaddr = lds_addr(Vt);
       auto pv = [&](auto SB) {
@@ -275,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(FwdArgs a) {
   }
 
   if (q0 >= S) return;
+  l_run += __shfl_xor(l_run, 32, 64);                  // lanes l and l + 32 hold the two key halves of one query; both saw the same m_run
   const float inv_l = 1.0f / l_run;
   if (lane < 32 && myq < S) {
     float* lp = a.lse + (((int64_t)g * H + h) * S + myq) * 2;

@@ -21,6 +21,14 @@ constexpr float PADL2 = 1e9f * 1.4426950408889634f;  // the reference's (1-mask)
 // copied at the join (the dK/dV loop carried 128 v_mov_b64 per tile for that reason)
 __device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
 
+// max over lanes l and l ^ 32 on the VALU (gfx950's v_permlane32_swap: the upper half of the first operand trades places with
+// the lower half of the second) instead of a ds_bpermute_b32 round trip in the softmax's dependent chain
+__device__ __forceinline__ float xor32_max(float v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  const auto sw = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+}
+
 __device__ __forceinline__ int swz(int r) { return ((r & 2) << 1) | ((r >> 2) & 3); }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
