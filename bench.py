@@ -191,10 +191,10 @@ class GemmTimer:
 
     @staticmethod
     def pmc_ratios():
-        """measured HBM bytes (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes: profiles/r03_b_hbm_traffic_norm_attention.json,
+        """measured HBM bytes (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes: profiles/r03_c_hbm_traffic_norm_attention.json,
         produced by tools/pmc_step_kernels.py + tools/parse_pmc_kernels.py) over the algorithmic bytes that `others` prices each
         kernel at, per kind and shape.  A lookup in tracked counter files, like `traffic` -- None when they are missing."""
-        path = os.path.join(ROOT, "profiles", "r03_b_hbm_traffic_norm_attention.json")
+        path = os.path.join(ROOT, "profiles", "r03_c_hbm_traffic_norm_attention.json")
         if not os.path.exists(path):
             return None
         k = json.load(open(path))["kernels"]
@@ -221,7 +221,7 @@ class GemmTimer:
                 ent["attn_bwd (dq + dkv, option attn_bwd1 = 0)"] = round((dq + dkv) / 9.0, 3)
                 ent["attn_bwd two-pass vs its minimum of 12"] = round((dq + dkv) / 12.0, 3)
             out[tag] = ent
-        return {"measured_over_algorithmic_hbm_bytes": out, "source": "profiles/r03_b_hbm_traffic_norm_attention.json"}
+        return {"measured_over_algorithmic_hbm_bytes": out, "source": "profiles/r03_c_hbm_traffic_norm_attention.json"}
 
     def summary(self, recs=None):
         tot_t, tot_f, n = 0.0, 0.0, 0

@@ -5,6 +5,7 @@ cd $R
 run python bench.py --no-cpu-baseline --with-optimizer --forward-only
 run python bench.py --no-cpu-baseline --heads 8
 run python bench.py --no-cpu-baseline --encoders 12 --batch-per-gpu 32
+run python bench.py --no-cpu-baseline --encoders 12 --steps 4 --warmup 2
 run python bench.py --no-cpu-baseline --encoders 12 --micro-batches 2 --steps 4 --warmup 2
 run python bench.py --no-cpu-baseline --model meant_vqa
 run python bench.py --no-cpu-baseline --model meant_vqa --batch-per-gpu 1024
