@@ -52,21 +52,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
   }
 
   float ra[LPT], rb[LPT];
-  auto load_tile = [&](int64_t k0) {
+  // Element addresses of a thread's LPT loads per operand, formed ONCE and advanced by one k-tile per load: the per-element form
+  // (two 64-bit multiplies, two compares, a select behind every load) was ~500 vector instructions per tile in front of its 32
+  // MFMAs, on a SIMD that holds a single wave.  Rows / columns past the edge read the tile's first row instead: what they
+  // produce is never stored.  Only a partial last k-tile (K not a multiple of BK) needs zeros and takes the checked form.
+  const TI* pa[LPT];
+  const TI* pb[LPT];
 #pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-      const int64_t m = m0 + am[i], k = k0 + ak[i];
-      ra[i] = (m < a.M && k < a.K) ? to_f(A[m * a.sA[2] + k * a.sA[3]]) : 0.f;
-      const int64_t n = n0 + bn[i], kb = k0 + bk[i];
-      rb[i] = (n < a.N && kb < a.K) ? to_f(B[kb * a.sB[2] + n * a.sB[3]]) : 0.f;
+  for (int i = 0; i < LPT; ++i) {
+    pa[i] = A + (m0 + (m0 + am[i] < a.M ? am[i] : 0)) * a.sA[2] + (int64_t)ak[i] * a.sA[3];
+    pb[i] = B + (int64_t)bk[i] * a.sB[2] + (n0 + (n0 + bn[i] < a.N ? bn[i] : 0)) * a.sB[3];
+  }
+  const int64_t step_a = (int64_t)BK * a.sA[3], step_b = (int64_t)BK * a.sB[2];
+  auto load_tile = [&](int64_t k0) {                  // the pointers stand on k0; leaves them on k0 + BK
+    if (k0 + BK <= a.K) {                             // block-uniform
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) { ra[i] = to_f(*pa[i]); rb[i] = to_f(*pb[i]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) {
+        ra[i] = k0 + ak[i] < a.K ? to_f(*pa[i]) : 0.f;
+        rb[i] = k0 + bk[i] < a.K ? to_f(*pb[i]) : 0.f;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) { pa[i] += step_a; pb[i] += step_b; }
   };
 
   f32x16 acc = {};
   const int64_t nk_all = (a.K + BK - 1) / BK, per = (nk_all + ksplit - 1) / ksplit;
   const int64_t kt0 = ks_ * per, nk = kt0 + per < nk_all ? kt0 + per : nk_all;
   if (kt0 >= nk) return;
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) { pa[i] += kt0 * step_a; pb[i] += kt0 * step_b; }
   load_tile(kt0 * BK);
+  // (A two-buffer form of this loop -- the stores of tile kt + 1 and the loads of tile kt + 2 dealt out over the 32 MFMA slots of
+  // tile kt, one barrier per tile -- measured 62 us against 44 us at (1536, 768, 768): hipcc cannot count vmcnt across the loop's
+  // back edge and waits for every load in flight in front of the first store of each tile.)
   for (int64_t kt = kt0; kt < nk; ++kt) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
