@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
   // (A two-buffer form of this loop -- the stores of tile kt + 1 and the loads of tile kt + 2 dealt out over the 32 MFMA slots of
   // tile kt, one barrier per tile -- measured 62 us against 44 us at (1536, 768, 768): hipcc cannot count vmcnt across the loop's
   // back edge and waits for every load in flight in front of the first store of each tile.)
+  // (All 64 fragment reads of a tile in front of its 32 MFMAs -- a scheduling barrier keeps hipcc from sinking them back --: 53 us.)
   for (int64_t kt = kt0; kt < nk; ++kt) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
