@@ -468,9 +468,18 @@ def _embed(mods, ids, dtype):
     return x
 
 
+HEAD_F32_MAX_CLASSES = 64
+
+
 def _head(mods, x):
-    """[norm, Linear, Sigmoid] heads (meant/meant.py:204): the sigmoid rides the GEMM epilogue."""
+    """[norm, Linear, Sigmoid] heads (meant/meant.py:204): the sigmoid rides the GEMM epilogue.
+    A head of at most HEAD_F32_MAX_CLASSES outputs is evaluated in fp32 in either tier (its [B, classes] product has no MFMA tile
+    to fill; the bf16 tier ran it on the exact-f32 generic kernel already and only STORED the probabilities as bf16).  That
+    rounding -- 2^-9 of a probability the loss differentiates -- was the largest single error of the tier's gradients: on the
+    full-dims golden one flipped output bit moved every gradient norm by 4 % (tools/debug_golden_c3.py)."""
     x = mods[0](x)
+    if x.dtype != torch.float32 and mods[1].weight.shape[0] <= HEAD_F32_MAX_CLASSES:
+        x = x.float()
     if isinstance(mods[2], nn.Sigmoid):
         return mods[1](x, epilogue=EPI_SIGMOID)
     return mods[2](mods[1](x))
