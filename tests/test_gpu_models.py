@@ -201,6 +201,35 @@ def test_autocast_selects_bf16_and_state_dict_roundtrip(dev):
     assert torch.equal(m3(ids, img, mask), o32)
 
 
+def test_small_class_heads_run_in_fp32_in_the_bf16_tier(dev):
+    """modules._head: a head of at most HEAD_F32_MAX_CLASSES outputs gets fp32 features and returns probabilities that were never
+    rounded to bf16 (the loss differentiates them: meant/meant.py:204 -> in_loop_train.py:222); wider heads stay on the bf16 GEMM"""
+    import meant_amd
+    from meant_amd import modules
+    seen = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            seen[name] = (inp[0].dtype, out.dtype)
+        return f
+    m = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2).to(dev).eval()
+    m.compute_dtype = torch.bfloat16
+    m.mlpHead[1].register_forward_hook(hook("small"))
+    ids = torch.randint(0, 100, (4, 3, 16), device=dev)
+    img = torch.randn(4, 3, 4, 32, 32, device=dev)
+    out = m(ids, img, torch.ones(4, 3, 16, device=dev))
+    assert seen["small"] == (torch.float32, torch.float32)
+    assert out.dtype == torch.float32 and not torch.equal(out, out.bfloat16().float())        # not bf16-quantised
+    out.sum().backward()
+    assert m.mlpHead[1].weight.grad is not None and torch.isfinite(m.mlpHead[1].weight.grad).all()
+    wide = modules.HEAD_F32_MAX_CLASSES + 8
+    m2 = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, wide, torch.nn.Embedding(100, 128), num_heads=2).to(dev).eval()
+    m2.compute_dtype = torch.bfloat16
+    m2.mlpHead[1].register_forward_hook(hook("wide"))
+    m2(ids, img, torch.ones(4, 3, 16, device=dev))
+    assert seen["wide"] == (torch.bfloat16, torch.bfloat16)
+
+
 @pytest.mark.gpu
 def test_model_on_device_batch_loader_float64(dev):
     """the reference's data path end to end (in_loop_train.py:579-639 -> :202-217): float64 graphs on the host,
