@@ -1228,6 +1228,24 @@ def patchify(images, p: int, dtype: torch.dtype, mean: float = 0.0, std: float =
 EMB_BF16_TABLE = os.environ.get("MEANT_EMB_BF16_TABLE", "1") == "1"     # 0: the bf16 tier's lookup reads the fp32 table (A/B measurements)
 
 
+EMB_PRESORT = os.environ.get("MEANT_EMB_PRESORT", "1") == "1"          # 0: sort the ids in backward (A/B measurements)
+_aux_streams = {}
+
+
+def _aux_stream(device):
+    """one extra HIP stream per device for small index work that should not sit on a compute stream's critical path"""
+    key = (device.type, device.index)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _emb_sorted_bwd_ok(n: int, d: int) -> bool:
+    """shapes whose embedding gradient is summed in sorted-id order (meant_embedding_bwd_sorted)"""
+    return d <= 1024 and d % 8 == 0 and (n >= 4096 or bool(_lib_option("deterministic")))
+
+
 class _Embedding(torch.autograd.Function):
     """nn.Embedding lookup (meant/meant.py:211) emitting the compute dtype directly."""
 
@@ -1249,7 +1267,21 @@ class _Embedding(torch.autograd.Function):
             tf = _c(table.detach().float())
             check(lib.meant_embedding_fwd(_p(tf), _p(ids_c), _p(out), n, d, V, F32 if dtype == torch.float32 else BF16, _stream()),
                   "embedding_fwd")
+        # The backward sums rows in the order of the sorted ids.  The sort (a radix block sort + ~20 merge launches, 0.2 ms of
+        # kernels that do not fill the chip) used to run in backward, where the embedding's gradient is the very last thing
+        # of the step; the ids are known now, so it runs here on a side stream, beside the forward's big kernels.
+        presort = None
+        if EMB_PRESORT and ctx.needs_input_grad[1] and _emb_sorted_bwd_ok(n, d):
+            main = torch.cuda.current_stream(ids_c.device)
+            side = _aux_stream(ids_c.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sorted_ids, order = torch.sort(ids_c.view(-1))
+                ev = torch.cuda.Event()
+                ev.record(side)
+            presort = (sorted_ids, order, ev)
         ctx.save_for_backward(ids_c)
+        ctx.presort = presort
         ctx.meta = (V, d)
         ctx.table = table                                # the Parameter itself: its gradient sink, if any, is looked up in backward
         _claim(table, "embedding")
@@ -1268,9 +1300,16 @@ class _Embedding(torch.autograd.Function):
             sink = None
         dtab = sink.view if sink is not None else torch.zeros((V, d), device=dout.device, dtype=torch.float32)
         n = ids_c.numel()
-        if d <= 1024 and d % 8 == 0 and (n >= 4096 or _lib_option("deterministic")):   # the other kernel is float atomics per token
+        if _emb_sorted_bwd_ok(n, d):                     # the other kernel is float atomics per token
             # index preparation (a sort of the token ids) is host-side plumbing; the reduction itself is the HIP kernel
-            sorted_ids, order = torch.sort(ids_c.view(-1))
+            if ctx.presort is not None:
+                sorted_ids, order, ev = ctx.presort
+                cur = torch.cuda.current_stream(dout.device)
+                cur.wait_event(ev)
+                sorted_ids.record_stream(cur)            # allocated on the side stream, read on this one
+                order.record_stream(cur)
+            else:
+                sorted_ids, order = torch.sort(ids_c.view(-1))
             nsl = sink.row_slices(ctx.table) if sink is not None else 1
             if nsl > 1:
                 # data parallel: the table's gradient is the last thing backward produces and two thirds of the bytes to reduce.
