@@ -454,6 +454,19 @@ def _pool_parts(compute_dtype, *stacks):
     return ops.meanpool_cat(*toks)
 
 
+POOL_OWN_STREAM = _os.environ.get("MEANT_POOL_OWN_STREAM", "1") == "1"
+
+
+def _pool_own_stream(compute_dtype, st):
+    """the pooled tail of ONE stack (mean over the sequence + the last Linear on the means) where the stack itself ran, instead of
+    both stacks' after the streams have joined: the vision stack finishes long before the language stack, so its two small fp32
+    products (and their three in backward, which autograd replays on this stream) leave the step's serial stretch.
+    Same values: the parts are rounded to the compute dtype before the concatenation instead of after it."""
+    if not POOL_OWN_STREAM or not (isinstance(st, tuple) and st[0].dim() == 2):
+        return st
+    return ops.pooled_linear_cat([st], compute_dtype)
+
+
 def _embed(mods, ids, dtype):
     """meant/meant.py:210-211.  A plain nn.Embedding is served by the HIP gather kernel; any other
     user module (e.g. HF RobertaEmbeddings) is called as is and its output cast."""
@@ -523,11 +536,13 @@ class meant(nn.Module):
             with torch.cuda.stream(side):
                 img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
                 img = _run_stack(self.visionEncoders, img, checkpoint=ck)
+                img = _pool_own_stream(dt, img)
         if side is not None and LANG_PRIORITY:
             hi = _hi_stream(images.device)
             hi.wait_stream(main)
             with torch.cuda.stream(hi):
                 words = _run_stack(self.languageEncoders, words, attention_mask, checkpoint=ck)
+                words = _pool_own_stream(dt, words)
             main.wait_stream(hi)
             for tt in (words if isinstance(words, tuple) else (words,)):
                 if tt is not None and tt.is_cuda:
@@ -542,7 +557,11 @@ class meant(nn.Module):
         else:
             img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
             img = _run_stack(self.visionEncoders, img, checkpoint=ck)
-        fused = _pool_parts(dt, words, img).view(B, self.lag, self.dim)
+        done = [torch.is_tensor(st) and st.dim() == 2 for st in (words, img)]       # pooled on its own stream already
+        if any(done):
+            fused = torch.cat([st if d_ else _pool_parts(dt, st) for st, d_ in zip((words, img), done)], dim=1).view(B, self.lag, self.dim)
+        else:
+            fused = _pool_parts(dt, words, img).view(B, self.lag, self.dim)
         for enc in self.temporal_encoding:
             fused = enc(fused)
         return _head(self.mlpHead, fused).squeeze(dim=1).float()
