@@ -928,15 +928,13 @@ def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads
     scores are unchanged (zeros add nothing to q.k, the scale stays 1/sqrt(dim)), and the zero columns of v give zero
     columns of the output, which are dropped again.  The padding is built from the parameters with differentiable ops,
     so their gradients need no special handling."""
-    if pre is not None and COMPOSE_AUX and x.is_cuda:
+    if pre is not None and COMPOSE_AUX and x.is_cuda and _aux_ready:      # only inside a model forward that ordered the side stream
         # The composed weight depends on parameters only: it is formed on a side stream, beside whatever the stack's own stream is
         # executing when the CPU gets here (0.07 ms of small fp32 products that sat in front of the q|k|v GEMM), and autograd
         # replays its backward -- two more such products, at the very end of a stack's backward -- on that side stream too.
         cur = torch.cuda.current_stream(x.device)
         aux = _aux_stream(x.device, 1)
-        if not _aux_ready:                                # parameters may have been written on this stream (an optimizer step):
-            aux.wait_stream(cur)                          # wait for it, unless the model ordered the side stream at its entry
-        with torch.cuda.stream(aux):
+        with torch.cuda.stream(aux):                      # (ordered after the parameters' last writers by ops.aux_begin)
             wqkv = torch.cat([wq, wk, wv], dim=0)
             bqkv = torch.cat([bq, bk, bv], dim=0)
             wqkv, bqkv = compose_linear(pre[0], pre[1], wqkv, bqkv)
