@@ -530,37 +530,33 @@ class meant(nn.Module):
         # stream of its forward op, so the backward passes overlap the same way.
         ck = _ckpt_setting(self)
         side = _side_stream(images.device) if (TWO_STREAMS and images.is_cuda and not ck) else None
-        try:
-            if side is not None:
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                ops.aux_begin(images.device)                 # (reset in the finally below, once both stacks are enqueued)
-                with torch.cuda.stream(side):
-                    img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
-                    img = _run_stack(self.visionEncoders, img, checkpoint=ck)
-                    img = _pool_own_stream(dt, img)
-            if side is not None and LANG_PRIORITY:
-                hi = _hi_stream(images.device)
-                hi.wait_stream(main)
-                with torch.cuda.stream(hi):
-                    words = _run_stack(self.languageEncoders, words, attention_mask, checkpoint=ck)
-                    words = _pool_own_stream(dt, words)
-                main.wait_stream(hi)
-                for tt in (words if isinstance(words, tuple) else (words,)):
-                    if tt is not None and tt.is_cuda:
-                        tt.record_stream(main)
-            else:
-                words = _run_stack(self.languageEncoders, words, attention_mask, checkpoint=ck)
-            if side is not None:
-                main.wait_stream(side)
-                for tt in (img if isinstance(img, tuple) else (img,)):
-                    if tt is not None and tt.is_cuda:
-                        tt.record_stream(main)
-            else:
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
                 img = _run_stack(self.visionEncoders, img, checkpoint=ck)
-        finally:
-            ops.aux_end()
+                img = _pool_own_stream(dt, img)
+        if side is not None and LANG_PRIORITY:
+            hi = _hi_stream(images.device)
+            hi.wait_stream(main)
+            with torch.cuda.stream(hi):
+                words = _run_stack(self.languageEncoders, words, attention_mask, checkpoint=ck)
+                words = _pool_own_stream(dt, words)
+            main.wait_stream(hi)
+            for tt in (words if isinstance(words, tuple) else (words,)):
+                if tt is not None and tt.is_cuda:
+                    tt.record_stream(main)
+        else:
+            words = _run_stack(self.languageEncoders, words, attention_mask, checkpoint=ck)
+        if side is not None:
+            main.wait_stream(side)
+            for tt in (img if isinstance(img, tuple) else (img,)):
+                if tt is not None and tt.is_cuda:
+                    tt.record_stream(main)
+        else:
+            img = self.patchEmbed(images.reshape(B * self.lag, *images.shape[2:]), dt)
+            img = _run_stack(self.visionEncoders, img, checkpoint=ck)
         done = [torch.is_tensor(st) and st.dim() == 2 for st in (words, img)]       # pooled on its own stream already
         if any(done):
             fused = torch.cat([st if d_ else _pool_parts(dt, st) for st, d_ in zip((words, img), done)], dim=1).view(B, self.lag, self.dim)

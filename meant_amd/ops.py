@@ -928,24 +928,10 @@ def qkv_attention(x, wq, bq, wk, bk, wv, bv, tables, key_mask, causal, num_heads
     scores are unchanged (zeros add nothing to q.k, the scale stays 1/sqrt(dim)), and the zero columns of v give zero
     columns of the output, which are dropped again.  The padding is built from the parameters with differentiable ops,
     so their gradients need no special handling."""
-    if pre is not None and COMPOSE_AUX and x.is_cuda and _aux_ready:      # only inside a model forward that ordered the side stream
-        # The composed weight depends on parameters only: it is formed on a side stream, beside whatever the stack's own stream is
-        # executing when the CPU gets here (0.07 ms of small fp32 products that sat in front of the q|k|v GEMM), and autograd
-        # replays its backward -- two more such products, at the very end of a stack's backward -- on that side stream too.
-        cur = torch.cuda.current_stream(x.device)
-        aux = _aux_stream(x.device, 1)
-        with torch.cuda.stream(aux):                      # (ordered after the parameters' last writers by ops.aux_begin)
-            wqkv = torch.cat([wq, wk, wv], dim=0)
-            bqkv = torch.cat([bq, bk, bv], dim=0)
-            wqkv, bqkv = compose_linear(pre[0], pre[1], wqkv, bqkv)
-        cur.wait_stream(aux)
-        wqkv.record_stream(cur)
-        bqkv.record_stream(cur)
-    else:
-        wqkv = torch.cat([wq, wk, wv], dim=0)
-        bqkv = torch.cat([bq, bk, bv], dim=0)
-        if pre is not None:
-            wqkv, bqkv = compose_linear(pre[0], pre[1], wqkv, bqkv)
+    wqkv = torch.cat([wq, wk, wv], dim=0)
+    bqkv = torch.cat([bq, bk, bv], dim=0)
+    if pre is not None:
+        wqkv, bqkv = compose_linear(pre[0], pre[1], wqkv, bqkv)
     D = wqkv.shape[0] // 3
     Dh = D // num_heads
     if x.dtype == torch.bfloat16 and Dh not in NATIVE_HEAD_DIMS and Dh < 128 and Dh % 8 == 0:
@@ -1242,30 +1228,15 @@ def patchify(images, p: int, dtype: torch.dtype, mean: float = 0.0, std: float =
 EMB_BF16_TABLE = os.environ.get("MEANT_EMB_BF16_TABLE", "1") == "1"     # 0: the bf16 tier's lookup reads the fp32 table (A/B measurements)
 
 
-COMPOSE_AUX = os.environ.get("MEANT_COMPOSE_AUX", "1") == "1"          # 0: weight compositions on the stack's own stream (A/B measurements)
 EMB_PRESORT = os.environ.get("MEANT_EMB_PRESORT", "1") == "1"          # 0: sort the ids in backward (A/B measurements)
 _aux_streams = {}
-_aux_ready = False
 
 
-def aux_begin(device) -> None:
-    """model entry: order the side stream after everything enqueued so far (parameter updates) ONCE, so that parameter-only work of
-    this forward pass (weight compositions) can start on it without waiting for the pass's own activations"""
-    global _aux_ready
-    if device.type == "cuda":
-        _aux_stream(device, 1).wait_stream(torch.cuda.current_stream(device))
-        _aux_ready = True
-
-
-def aux_end() -> None:
-    global _aux_ready
-    _aux_ready = False
-
-
-def _aux_stream(device, which: int = 0):
-    """extra HIP streams per device for small work that should not sit on a compute stream's critical path
-    (0: index preparation, 1: parameter-only products)"""
-    key = (device.type, device.index, which)
+def _aux_stream(device):
+    """one extra HIP stream per device for small index work that should not sit on a compute stream's critical path.
+    (ONE: a fifth stream next to main / vision / language / this one -- tried for the weight compositions, which depend on
+    parameters only -- cost the step 11 %, 2800 against 3140 samples/s, whether or not anything ran on it)"""
+    key = (device.type, device.index)
     st = _aux_streams.get(key)
     if st is None:
         st = _aux_streams[key] = torch.cuda.Stream(device=device)
