@@ -521,6 +521,8 @@ class meant(nn.Module):
     def forward(self, tweets, images, attention_mask=None):
         dt = resolve_compute_dtype(self, images)
         B = images.shape[0]
+        if images.is_cuda and TWO_STREAMS:
+            ops.set_index_stream(images.device, _side_stream(images.device))     # the id sort rides the vision stream
         words = _embed(self.embedding, tweets.reshape(B * self.lag, tweets.shape[2]), dt)
         if attention_mask is not None:
             attention_mask = attention_mask.reshape(B * self.lag, attention_mask.shape[2])

@@ -1230,6 +1230,13 @@ EMB_BF16_TABLE = os.environ.get("MEANT_EMB_BF16_TABLE", "1") == "1"     # 0: the
 
 EMB_PRESORT = os.environ.get("MEANT_EMB_PRESORT", "1") == "1"          # 0: sort the ids in backward (A/B measurements)
 _aux_streams = {}
+_aux_override = {}                                  # (device type, index) -> a stream the model already owns (set_index_stream)
+
+
+def set_index_stream(device, stream) -> None:
+    """let small index work (the id sort of the embedding backward) ride a stream the model runs anyway -- `meant` hands over its
+    vision stream -- instead of one more stream of its own: same step time, and one stream fewer towards the cliff described below"""
+    _aux_override[(device.type, device.index)] = stream
 
 
 def _aux_stream(device):
@@ -1237,6 +1244,8 @@ def _aux_stream(device):
     (ONE: a fifth stream next to main / vision / language / this one -- tried for the weight compositions, which depend on
     parameters only -- cost the step 11 %, 2800 against 3140 samples/s, whether or not anything ran on it)"""
     key = (device.type, device.index)
+    if _aux_override.get(key) is not None:
+        return _aux_override[key]
     st = _aux_streams.get(key)
     if st is None:
         st = _aux_streams[key] = torch.cuda.Stream(device=device)
