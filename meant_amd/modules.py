@@ -58,7 +58,11 @@ def _side_stream(device):
 # With TWO_STREAMS the LANGUAGE stack -- the longer of the two, i.e. the step's critical path -- runs on a high-priority stream of its
 # own, so that its kernels are placed ahead of the vision stack's when both are waiting for CUs: 43.00 -> 42.90 ms median over three
 # alternating pairs of 30-step runs on one box (+0.2 %; MEANT_LANG_PRIORITY=0 runs it on the caller's stream as before)
-LANG_PRIORITY = _os.environ.get("MEANT_LANG_PRIORITY", "1") != "0"
+# Default: on for a single-process run, OFF under a multi-process launch (WORLD_SIZE > 1): there the gradient reducer's launch stream
+# and RCCL's own stream come on top of main + vision, and a fifth stream in the process cost this step 11 % where it was measured
+# (one GPU).  +0.2 % is not worth that risk unmeasured; MEANT_LANG_PRIORITY=1 forces it on.
+_multi = int(_os.environ.get("WORLD_SIZE", "1") or "1") > 1
+LANG_PRIORITY = _os.environ.get("MEANT_LANG_PRIORITY", "0" if _multi else "1") != "0"
 _HI = {}
 
 
