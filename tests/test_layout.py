@@ -121,6 +121,30 @@ def test_norm_linear_fold_rule(monkeypatch):
     assert ops.fold_wanted()
 
 
+def test_scheduling_switches_host_logic():
+    """host-side rules of the step's scheduling (no GPU): which embedding gradients are summed in sorted-id order (and therefore have
+    their ids sorted in forward), what a stack's own-stream pooling leaves alone, the language stack's stream under a multi-process launch"""
+    import subprocess
+    import sys
+    import torch
+    from meant_amd import modules, ops
+    assert ops._emb_sorted_bwd_ok(786432, 768) and ops._emb_sorted_bwd_ok(4096, 768)
+    assert not ops._emb_sorted_bwd_ok(4095, 768)              # few tokens: the float-atomics kernel (unless option deterministic)
+    assert not ops._emb_sorted_bwd_ok(786432, 2048) and not ops._emb_sorted_bwd_ok(786432, 772)
+    toks = torch.zeros(2, 5, 8)
+    assert modules._pool_own_stream(torch.float32, toks) is toks                    # a token tensor: pooled later, the literal way
+    part = (torch.zeros(2, 5, 8), torch.zeros(2, 5, 8), torch.zeros(8, 8), None)
+    assert modules._pool_own_stream(torch.float32, part) is part                    # (h, x, W, b) tokens: pool_linear_cat's job
+    code = "import meant_amd.modules as m; print(int(m.LANG_PRIORITY))"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("MEANT_LANG_PRIORITY", None)
+    for ws, want in (("1", "1"), ("8", "0")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(env, WORLD_SIZE=ws), capture_output=True, text=True, cwd=ROOT)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == want, (ws, out.stdout, out.stderr[-300:])
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, WORLD_SIZE="8", MEANT_LANG_PRIORITY="1"), capture_output=True, text=True, cwd=ROOT)
+    assert out.stdout.strip().splitlines()[-1] == "1"
+
+
 def test_rotary_tables_match_golden(golden):
     """host-side table builder (CPU part of the rotary path) against the reference's rotated vectors"""
     import meant_amd
