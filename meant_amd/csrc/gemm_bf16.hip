@@ -842,6 +842,567 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256s_kernel(GemmBf16Args a
 }
 
 // ------------------------------------------------------------------------------------------------
+// Epilogue of one wave's 128 x 64 accumulator block of a 256 x 256 tile (the streaming kernels' per-wave patch epilogue as a
+// function): accumulators -> the wave's two private 4 KiB LDS patches (fp32, XOR-swizzled, alternating per 16-row round) ->
+// 128-byte row segments.  No workgroup barrier inside; the caller guarantees that nobody else touches the patches.
+// Lane layout in: acc[i][j] = C[i*16 + frow][j*16 + 4*fkg .. +3]; out: lane l owns 8 consecutive columns (l & 7) * 8 of row
+// (l >> 3) + 8h, i.e. one store instruction writes 8 complete 128-byte lines.  Patch I/O goes through inline asm: hipcc does
+// not know the DMA ring is quiescent there and would put a vmcnt(0) -- a full drain of the output stores and of the prefetch in
+// flight -- in front of every plain LDS store.
+#ifdef PP_LAB_STAMP
+// lab build only (tools/lab/stamp_pp.py): s_memtime sums of waves 0 (leader) and 4 (follower) per workgroup:
+// 0 steps kt > 0 (without the wait) | 1 steps kt == 0 | 2 end-of-step vmcnt wait | 3 epilogue until the bias is there | 4 epilogue rounds |
+// 5 barriers behind the epilogue | 6 steps | 7 tiles | 8 total ticks | 9 total s_memrealtime ticks (100 MHz)
+constexpr int PP_LAB_MAX_WG = 256;
+__device__ unsigned long long g_pp_stamp[PP_LAB_MAX_WG * 2 * 16];
+__device__ __forceinline__ unsigned long long pp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define PPSTAMP(i) { const unsigned long long n__ = pp_now(); lab_acc[i] += n__ - lab_t; lab_t = n__; }
+#define PPSTAMP_ARGS , unsigned long long (&lab_acc)[10], unsigned long long& lab_t
+#define PPSTAMP_PASS , lab_acc, lab_t
+#else
+#define PPSTAMP(i)
+#define PPSTAMP_ARGS
+#define PPSTAMP_PASS
+#endif
+// Epilogue modes: what the launcher knows about a launch is a TEMPLATE parameter, so that the eight rounds are straight-line code.
+// With the options as run-time flags every `if (a.residual)` / `if (a.preact)` ... is a branch with loads on one side, and at each
+// join hipcc waits for vmcnt(0): every round then waited for the previous round's output stores to be ACKNOWLEDGED by memory
+// (2.5 k cycles per round, 20 k of a 64 k-cycle tile at K = 768: round 4, tools/lab/stamp_pp.py) -- a store is fire-and-forget
+// only while nothing behind it asks for the counter.
+enum { NTE_PLAIN = 0, NTE_RES, NTE_GELU_PRE, NTE_ROT, NTE_EXT, NTE_GENERIC };
+#define GAS __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const GAS T* gp(const T* p) { return (const GAS T*)p; }
+template <typename T> __device__ __forceinline__ GAS T* gpw(T* p) { return (GAS T*)p; }
+
+template <int MODE>
+__device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4 (&acc)[8][4], float* patch0, float* patch1, int64_t m0,
+                                                    int64_t n0, int wm, int wn, int lane PPSTAMP_ARGS) {
+  constexpr bool ROT = MODE == NTE_ROT, EXT = MODE == NTE_EXT, GEN = MODE == NTE_GENERIC || EXT;
+  // compile-time constants in the specialised modes, run-time flags in the two generic ones
+  const bool f_res = MODE == NTE_RES || (GEN && a.residual != nullptr);
+  const bool f_pre = MODE == NTE_GELU_PRE || (GEN && a.preact != nullptr);
+  const bool f_gelu = MODE == NTE_GELU_PRE || (GEN && (a.epilogue & MEANT_EPI_GELU));
+  const bool f_sig = MODE == NTE_GENERIC && (a.epilogue & MEANT_EPI_SIGMOID);
+  const int frow = lane & 15, fkg = lane >> 4;
+  float* patch[2] = {patch0, patch1};
+  const int orow = lane >> 3, oc = lane & 7;
+  const int64_t n = n0 + wn * 64 + oc * 8;
+  const int64_t mrow = m0 + wm * 128 + orow;          // this lane's row of round 0, h = 0
+  float bias[8];
+  if (a.bias) {
+    const f32x4 b0 = *gp(reinterpret_cast<const f32x4*>(a.bias + n)), b1 = *gp(reinterpret_cast<const f32x4*>(a.bias + n + 4));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = e < 4 ? b0[e] : b1[e - 4];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  }
+  const unsigned pw[2] = {lds_addr(patch[0]) + frow * 256, lds_addr(patch[1]) + frow * 256};
+  // rotary epilogue (fused q|k|v projection): the lane's 8 columns sit at a fixed place c of a q or k head for the whole tile,
+  // only the position m mod S changes.  vmcnt retires in order, so a table load issued after a round's output stores would wait
+  // for those stores to be acknowledged: the operands of round r+1 are requested BEFORE the stores of round r go out.
+  bool rot_on = false;
+  const float *tabA = nullptr, *tabB = nullptr;
+  if (ROT) {
+    const int sec = (int)(n / a.rot_D);
+    const int c = (int)((n - (int64_t)sec * a.rot_D) % a.rot_Dh);
+    rot_on = sec < 2 && c < a.rot_R;
+    tabA = (sec ? a.rot_ka : a.rot_qa) + c;
+    tabB = (sec ? a.rot_kb : a.rot_qb) + c;
+  }
+  f32x4 ta[2][2], tb[2][2];                        // [h][half]
+  bf16x8 xres[2] = {}, xsub[2] = {};
+  float xrs[2] = {1.f, 1.f}, xkc[2] = {0.f, 0.f};
+  f32x4 xbr[2][2] = {};
+  // one register set: a round's operands are consumed (both rows finished), THEN the next round's are requested into the same
+  // registers, THEN the round's stores go out -- loads never queue behind stores
+  auto load_ops = [&](int i) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t m = mrow + i * 16 + 8 * h;
+      if (ROT) {
+        if (rot_on) {
+          const int64_t o = (int64_t)(m % a.rot_S) * a.rot_R;
+          ta[h][0] = *gp(reinterpret_cast<const f32x4*>(tabA + o));
+          ta[h][1] = *gp(reinterpret_cast<const f32x4*>(tabA + o + 4));
+          tb[h][0] = *gp(reinterpret_cast<const f32x4*>(tabB + o));
+          tb[h][1] = *gp(reinterpret_cast<const f32x4*>(tabB + o + 4));
+        }
+      } else {
+        if (f_res) xres[h] = __builtin_nontemporal_load(gp(reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n)));
+        if (EXT) {
+          if (a.row_scale) xrs[h] = *gp(a.row_scale + m);
+          if (a.sub) {
+            xsub[h] = *gp(reinterpret_cast<const bf16x8*>(a.sub + m * a.ldsub + n));
+            xkc[h] = *gp(a.sub_coef + m);
+          }
+          if (a.bres) {
+            const float* bp = a.bres + (m / a.bres_rows) * a.N + n;
+            xbr[h][0] = *gp(reinterpret_cast<const f32x4*>(bp));
+            xbr[h][1] = *gp(reinterpret_cast<const f32x4*>(bp + 4));
+          }
+        }
+      }
+    }
+  };
+  load_ops(0);
+#ifdef PP_LAB_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PPSTAMP(3)
+#endif
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int u = i & 1;                           // alternate between the two patches
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      asm volatile("ds_write_b128 %0, %1" ::"v"(pw[u] + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
+    // both rows of the round come back in ONE asm statement that also waits for them: hipcc does not know an asm ds_read is
+    // asynchronous and may copy its destination before a wait that sits in a later statement (tools/isa_inflight_check.py)
+    f32x4 lo[2], hi[2];
+    {
+      const unsigned b0 = lds_addr(patch[u]) + orow * 256, b1 = b0 + 8 * 256;
+      const int r0 = orow, r1 = orow + 8;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1])
+                   : "v"(b0 + (((2 * oc) ^ r0) << 4)), "v"(b0 + (((2 * oc + 1) ^ r0) << 4)), "v"(b1 + (((2 * oc) ^ r1) << 4)),
+                     "v"(b1 + (((2 * oc + 1) ^ r1) << 4))
+                   : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 outv[2], prev[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(e < 4 ? lo[h][e] : hi[h][e - 4], EXT ? xrs[h] : 1.0f, bias[e]);
+      if (f_pre) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) prev[h][e] = (bf16)v[e];
+      }
+      if (ROT && rot_on) rot_apply8(v, ta[h][0], ta[h][1], tb[h][0], tb[h][1]);
+      if (f_gelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+      }
+      if (f_sig) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+      }
+      if (f_res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)xres[h][e];
+      }
+      if (EXT) {
+        if (a.sub) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(-xkc[h], (float)xsub[h][e], v[e]);
+        }
+        if (a.bres) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(a.bres_scale, e < 4 ? xbr[h][0][e] : xbr[h][1][e - 4], v[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) outv[h][e] = (bf16)v[e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < 8) load_ops(i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t m = mrow + i * 16 + 8 * h;
+#ifndef PP_LAB_NOSTORE
+      if (f_pre) *gpw(reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n)) = prev[h];
+      *gpw(reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n)) = outv[h];
+#else
+      asm volatile("" ::"v"(outv[h]), "v"(prev[h]));
+#endif
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the wave is out of its patches
+  PPSTAMP(4)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming NT kernel, PING-PONG form (round 4).  Same tile (256 x 256 x 64), same 8 waves (2 along M x 4 along N, 128 x 64 per
+// wave), same five-slot ring, tile walk and per-wave patch epilogue as gemm_bf16_nt256s_kernel -- what changes is WHEN the two
+// waves of a SIMD do what.  In the kernel above all eight waves run in lock step: both waves of a SIMD read fragments at the same
+// time (matrix pipe idle) and then both queue MFMAs (LDS and the address unit idle); a K-step measures 1.65 us against 1.08 us
+// of MFMA time.  Here the workgroup is two GROUPS of four waves, one wave per SIMD each: the LEADER (waves 0-3, rows 0..127 of the
+// tile) and the FOLLOWER (waves 4-7, rows 128..255), which runs the same program ONE BARRIER INTERVAL behind.  A K-step is P
+// phases (P = 2: one 64-row half of the wave's block x all of K = 64, 32 MFMAs; P = 4: half x k-half, 16 MFMAs); a phase is a
+// LOAD half (the phase's fragment reads and its share of the prefetch stream's LDS-DMA pieces) and an MFMA half, with a workgroup
+// barrier after each.  The one-interval lag puts every MFMA half of one group beside a LOAD half of the other: a SIMD's matrix
+// pipe always has exactly one wave feeding it, and fragment reads, DMA issue and address arithmetic of its partner run underneath
+// (cdna_hip_programming.md "The 256^2 8-phase template"; MI355X_MICROARCH.md "Two waves per SIMD", items 1, 5, 9).
+// A wave issues one instruction every ~4-5 cycles, so a LOAD half hides only while it stays well under (MFMAs per phase) x 16 / 4.5
+// instructions: the prefetch cursors are branch-free scalar selects, DMA pieces use the SGPR-base form (no per-piece VALU), and
+// everything the epilogue needs is re-read from the kernarg segment per tile instead of living in SGPRs across the K-loop.
+//
+// Barrier intervals of K-step n, P = 2 (I = 4n + ...), L/M = load / MFMA half of phase p:
+//     leader:    L0 M0 L1 M1          follower:  -- L0 M0 L1 | M1
+// Prefetch stream (wave w owns pieces 4w .. 4w+3 of every tile: rows 32w .. 32w+31): the first half of a step's phases carries
+// B of step n+1 (weights: L2 hits, needed at the next step's L0), the second half A of step n+2 (from HBM: more than a step of
+// lead).  Each wave waits for its own pieces of step n+1 with a counted vmcnt (its four youngest requests, A of step n+2, stay
+// in flight) just before the barrier in front of the leader's next L0: the leader at the end of its last M, the follower at the end
+// of its last L.
+// Slot reuse: B of step n+1 goes into the slot of A of step n-1, each wave into rows only its OWN group read (the leader's last
+// reads of them are two intervals old, the follower's one and complete -- it has issued the MFMAs that needed them); A of step
+// n+2 goes into the slot of B of step n-1, last read in the follower's first load half of that step.
+// Tile end: the leader runs its epilogue in the interval in which the follower issues its last MFMAs and then runs its own (the
+// two epilogues overlap), one barrier, then the leader's L0 of the next tile while the follower idles one interval.  The patches
+// live in the two slots of the tile's last step, each wave inside rows only its own group read; the DMA into those slots starts
+// behind that barrier.  After the last tile the cursors keep prefetching (valid rows of the last tile, never read): no branch
+// in the K-loop distinguishes it.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds) {   // sbase, lds: wave-uniform
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+typedef const __attribute__((address_space(4))) unsigned* kernarg_words_t;
+static_assert(sizeof(GemmBf16Args) % 4 == 0, "kernarg copy by words");
+
+#ifdef PP_LAB_STAMP2
+// second lab build (tools/lab/stamp_pp.py with PROBE_FINE=1), P = 2 only: s_memtime sums per half phase of waves 0 and 4:
+// 0 L0 | 1 barrier behind L0 | 2 M0 | 3 barrier behind M0 | 4 L1 (+ follower's wait) | 5 barrier behind L1 | 6 M1 | 7 rest of the step up
+// to the next L0 (leader's wait, cursors, barrier) | 8 steps.  Stamps taken while LDS reads are in flight are not waited for on the
+// spot (the wait would serialise behind the reads): they are read behind the next lgkmcnt(0) the code has anyway.
+__device__ unsigned long long g_pp_stamp2[256 * 2 * 16];
+#define PP2_NOW(v) asm volatile("s_memtime %0" : "=s"(v)::"memory")
+#define PP2_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PP2_BEGIN() { PP2_NOW(f_a); PP2_SYNC(); f_acc[7] += f_a - f_e; }
+#define PP2_BEGIN2(i) { PP2_NOW(f_a); PP2_SYNC(); f_acc[i] += f_a - f_e; }
+#define PP2_L_END() { PP2_NOW(f_b); }
+#define PP2_M_BEGIN(i) { PP2_NOW(f_c); PP2_SYNC(); f_acc[i] += f_b - f_a; f_acc[i + 1] += f_c - f_b; }
+#define PP2_M_END(i) { PP2_NOW(f_e); PP2_SYNC(); f_acc[i] += f_e - f_c; }
+#else
+#define PP2_BEGIN()
+#define PP2_BEGIN2(i)
+#define PP2_L_END()
+#define PP2_M_BEGIN(i)
+#define PP2_M_END(i)
+#endif
+template <int MODE, int P>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a, int ntm, int ntn, TileSched* __restrict__ sched, int mode) {
+  static_assert(P == 2 || P == 4, "phases per K-step");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool leader = wm == 0;
+  const int nk = (int)(a.K / BK);
+  const int ntiles = ntm * ntn, G = gridDim.x;
+  const int CH = G >> 3, xcd = blockIdx.x & 7;
+  int tile = xcd * CH + (blockIdx.x >> 3);
+  const bool dynamic = sched != nullptr && nk >= 8;
+  auto leave = [&]() {
+    if (sched && threadIdx.x == 0) {
+      if (atomicAdd(&sched->done, 1u) == (unsigned)G - 1u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sched->next[i] = 0;
+        sched->done = 0;
+      }
+    }
+  };
+  if (tile >= ntiles) { leave(); return; }
+  auto tile_of = [&](int x, unsigned k) { return (int)((k / (unsigned)CH) * (unsigned)G + (unsigned)(x * CH) + k % (unsigned)CH); };
+
+  // DMA: piece q (1 KiB = 8 rows of 128 B) of a 32-piece tile; wave w owns pieces 4w + p, p = 0..3.  Row r of the tile keeps its
+  // 16-byte chunk c at slot c ^ ((r >> 1) & 7): for r = 32w + 8p + (lane >> 3) that is (lane & 7) ^ (lane >> 4 & 3) ^ 4 (p & 1).
+  const int rl = lane >> 3;
+  const int c0 = (lane & 7) ^ (rl >> 1);
+  unsigned vA[4], vB[4];                               // byte offsets of this lane's 16 bytes of piece p from the tile's origin
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    vA[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.lda + (c0 ^ ((p & 1) << 2)) * 8) * 2);
+    vB[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.ldb + (c0 ^ ((p & 1) << 2)) * 8) * 2);
+  }
+  const unsigned lds0 = lds_addr(smem) + wave * 4096;  // this wave's first piece inside slot 0
+  auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
+    const int tm = t / ntn, tn = t - tm * ntn;
+    m0 = (int64_t)tm * B2;
+    m0 = m0 + B2 <= a.M ? m0 : a.M - B2;               // ragged M: the last row tile is moved up to END at row M (see the launcher)
+    n0 = (int64_t)tn * B2;
+    pa = a.A + m0 * a.lda;
+    pb = a.B + n0 * a.ldb;
+  };
+
+  const bf16 *pA, *pB, *pAn, *pBn;                     // origins of this tile and of the next one (the same when there is none)
+  int64_t m0, n0, m0n, n0n;
+  origin(tile, pA, pB, m0, n0);
+  int next = dynamic ? -1 : tile + G;
+  bool has_next = !dynamic && next < ntiles;
+  pAn = pA; pBn = pB; m0n = m0; n0n = n0;
+  if (has_next) origin(next, pAn, pBn, m0n, n0n);
+  unsigned* mailbox = sched ? &sched->mailbox[blockIdx.x] : nullptr;
+
+  // Start stagger (mode bit 8).  All workgroups start together and a tile takes every CU the same time, so all 256 CUs reach their
+  // epilogues -- 32 MiB of output stores -- in the same few microseconds and then sit in the store queue (measured: 20 k of a tile's
+  // 64 k cycles at K = 768) while HBM writes idle for the rest of the tile.  Workgroup j of the G / 8 on its XCD therefore starts
+  // j / (G / 8) of a tile time late: the bursts of different CUs fall beside other CUs' K-loops.  The tiles are handed out by counters,
+  // so a late starter simply ends up with fewer of them.
+  if (mode & 0x100) {
+    const int j = blockIdx.x >> 3;                     // position inside the XCD's group of CH workgroups
+    // a K-step is ~1.5 us ~ 3000 cycles, an epilogue ~ 4 of them; s_sleep 127 ~ 8128 cycles
+    const int naps = (int)(((int64_t)(nk + 4) * 3000 * j / CH) >> 13);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  // prologue: A_0, B_0, A_1 (four pieces per wave and tile); the first two must have landed
+#pragma unroll
+  for (int p = 0; p < 4; ++p) glds16_s(pA, vA[p], lds0 + p * 1024);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) glds16_s(pB, vB[p], lds0 + T2_BYTES + p * 1024);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) glds16_s(pA + BK, vA[p], lds0 + 2 * T2_BYTES + p * 1024);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (!leader) {                                       // the follower's one-interval lag
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // prefetch cursors: what the B pieces (one step ahead) and the A pieces (two steps ahead) of the CURRENT step read
+  const bf16* qB = pB + BK;
+  const bf16* qA = pA + 2 * BK;
+
+#define PP_BAR()                          \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+#ifdef PP_LAB_STAMP
+  unsigned long long lab_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long lab_t = pp_now();
+  const unsigned long long lab_t0 = lab_t, lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef PP_LAB_STAMP2
+  unsigned long long f_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long f_a = 0, f_b = 0, f_c = 0, f_e = 0;
+  PP2_NOW(f_e); PP2_SYNC();
+#endif
+  const int frow = lane & 15, fkg = lane >> 4;
+  // fragment read offsets inside a slot: row i*16 + frow, chunk (ks*4 + fkg) ^ ((row >> 1) & 7); i adds 2048 bytes, ks flips bit 6
+  const unsigned fo0 = (unsigned)(frow * 128 + ((fkg ^ (frow >> 1)) << 4));
+  const unsigned foA[2] = {fo0 + wm * 16384, (fo0 ^ 64u) + wm * 16384};
+  const unsigned foB[2] = {fo0 + wn * 8192, (fo0 ^ 64u) + wn * 8192};
+  int kspecial = dynamic ? 3 : -1;
+  int sA = 0;                                          // ring slot of the current step's A tile; B sits in the next one
+  for (;;) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int sB = sA + 1 == RING ? 0 : sA + 1;
+      const int s3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, s4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
+      // tile draw, part 1 (see TileSched): requests only; they are older than this step's DMA pieces, so the counted wait that
+      // ends the step covers them.  hipcc does not know these registers are in flight (tests/test_isa_guards.py checks the ISA).
+      // Everything about the draw sits behind ONE scalar test per step: the load halves hide under the partner's MFMAs only while
+      // they stay short (a wave issues an instruction every ~4-5 cycles).
+      unsigned mail = 0, ticket = 0;
+      const bool special = kt == kspecial;              // kspecial: 3, then 5, then never (-1 without the dynamic hand-out)
+      bool drawer = false;
+      const bool own = !((mode & 0xff) == 3 && xcd != 0);
+      if (special) {
+        if (kt == 5) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(mail) : "v"(mailbox) : "memory");
+        else {
+          drawer = wave == 4 && lane == 0;
+          if (drawer && own) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(&sched->next[xcd]), "v"(1u) : "memory");
+        }
+      }
+
+      const unsigned aoff = (unsigned)sA * T2_BYTES, boff = (unsigned)sB * T2_BYTES;
+      const unsigned dB = lds0 + (unsigned)s3 * T2_BYTES, dA = lds0 + (unsigned)s4 * T2_BYTES;
+      bf16x8 aq[2][4], bq[2][4];
+      auto ldA = [&](int ih, int ks, bf16x8 (&d)[4]) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) d[ii] = *reinterpret_cast<const bf16x8*>(smem + aoff + foA[ks] + (ih * 4 + ii) * 2048);
+      };
+      auto ldB = [&](int ks, bf16x8 (&d)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = *reinterpret_cast<const bf16x8*>(smem + boff + foB[ks] + j * 2048);
+      };
+      auto mm = [&](int ih, const bf16x8 (&av)[4], const bf16x8 (&bv)[4]) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[ih * 4 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[ii], acc[ih * 4 + ii][j], 0, 0, 0);   // swapped: acc = C^T tile
+      };
+      auto wait_step = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
+      if (P == 2) {
+        // ---- phase 0: rows 0..63 of the wave's block, both k-halves ----------------------------------------------------
+        PP2_BEGIN()
+#pragma unroll
+        for (int p = 0; p < 4; ++p) glds16_s(qB, vB[p], dB + p * 1024);
+        ldB(0, bq[0]); ldB(1, bq[1]);
+        ldA(0, 0, aq[0]); ldA(0, 1, aq[1]);
+        PP2_L_END()
+        PP_BAR();
+        PP2_M_BEGIN(0)
+        __builtin_amdgcn_s_setprio(1);
+        mm(0, aq[0], bq[0]); mm(0, aq[1], bq[1]);
+        __builtin_amdgcn_s_setprio(0);
+        PP2_M_END(2)
+        PP_BAR();
+        // ---- phase 1: rows 64..127 ------------------------------------------------------------------------------------
+        PP2_BEGIN2(3)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) glds16_s(qA, vA[p], dA + p * 1024);
+        ldA(1, 0, aq[0]); ldA(1, 1, aq[1]);
+        PP2_L_END()
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_LAB_STAMP
+        if (!leader) { if (kt) PPSTAMP(0) else PPSTAMP(1) }
+#endif
+        if (!leader) wait_step();                      // follower: its pieces of the next step must be in before the leader's L0
+#ifdef PP_LAB_STAMP
+        if (!leader) PPSTAMP(2)
+#endif
+        PP_BAR();
+        PP2_M_BEGIN(4)
+        __builtin_amdgcn_s_setprio(1);
+        mm(1, aq[0], bq[0]); mm(1, aq[1], bq[1]);
+        __builtin_amdgcn_s_setprio(0);
+        PP2_M_END(6)
+      } else {
+        // ---- phase 0: rows 0..63, k 0..31 ------------------------------------------------------------------------------
+        glds16_s(qB, vB[0], dB); glds16_s(qB, vB[1], dB + 1024);
+        ldB(0, bq[0]); ldA(0, 0, aq[0]);
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        mm(0, aq[0], bq[0]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- phase 1: rows 64..127, k 0..31 ----------------------------------------------------------------------------
+        glds16_s(qB, vB[2], dB + 2048); glds16_s(qB, vB[3], dB + 3072);
+        ldA(1, 0, aq[1]);
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        mm(1, aq[1], bq[0]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- phase 2: rows 0..63, k 32..63 -----------------------------------------------------------------------------
+        glds16_s(qA, vA[0], dA); glds16_s(qA, vA[1], dA + 1024);
+        ldB(1, bq[1]); ldA(0, 1, aq[0]);
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        mm(0, aq[0], bq[1]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- phase 3: rows 64..127, k 32..63 ---------------------------------------------------------------------------
+        glds16_s(qA, vA[2], dA + 2048); glds16_s(qA, vA[3], dA + 3072);
+        ldA(1, 1, aq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!leader) wait_step();
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        mm(1, aq[1], bq[1]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_LAB_STAMP
+      if (leader) { if (kt) PPSTAMP(0) else PPSTAMP(1) }
+#endif
+      if (leader) wait_step();
+#ifdef PP_LAB_STAMP
+      if (leader) PPSTAMP(2)
+      lab_acc[6] += 1;
+#endif
+#ifdef PP_LAB_STAMP2
+      f_acc[8] += 1;
+#endif
+      // the follower's last MFMAs of a tile and its epilogue share one interval (see the header)
+      if (leader || kt + 1 < nk) PP_BAR();
+      // ---- bookkeeping of the step, BEHIND its last barrier: it runs beside the partner group's MFMA half -------------------------
+      // cursors for the next step: one K-block on, or into the next tile when the step they feed is one (B: step kt + 2 of this
+      // tile does not exist; A: step kt + 3)
+      qB = kt + 2 == nk ? pBn : qB + BK;
+      qA = kt + 3 == nk ? pAn : qA + BK;
+      if (special) {
+        asm volatile("" : "+v"(mail), "+v"(ticket) : : "memory");
+        // tile draw, part 2: the answers are here (the step's counted wait covered them)
+        if (drawer) {
+          int id = own ? tile_of(xcd, (unsigned)CH + ticket) : ntiles;
+          if (id >= ntiles) {
+            unsigned seen[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) seen[x] = __hip_atomic_load(&sched->next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int att = 1; id >= ntiles && att < 8; ++att) {
+              const int x2 = (xcd + att) & 7;
+              if (tile_of(x2, (unsigned)CH + seen[x2]) >= ntiles) continue;
+              id = tile_of(x2, (unsigned)CH + atomicAdd(&sched->next[x2], 1u));
+              if (id < ntiles) atomicAdd(&sched->steals, 1u);
+            }
+          }
+          const unsigned pub = id < ntiles ? (unsigned)id : 0xffffffffu;
+          asm volatile("global_store_dword %0, %1, off sc1" ::"v"(mailbox), "v"(pub) : "memory");
+        }
+        if (kt == 5) {
+          const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)mail);
+          next = (mode & 0xff) == 2 ? (tile + G < ntiles ? tile + G : -1) : (int)got;
+          has_next = next >= 0;
+          if (has_next) origin(next, pAn, pBn, m0n, n0n);
+        }
+        kspecial = kt == 3 ? 5 : -1;
+      }
+      sA = sA + 2 >= RING ? sA + 2 - RING : sA + 2;
+    }
+    kspecial = dynamic ? 3 : -1;
+
+    // ---- epilogue: the two slots of the tile's last step are free; each wave's patches lie inside rows only its own group read.
+    // Its arguments come fresh from the kernarg segment (the pointer is laundered so that hipcc cannot keep them in SGPRs
+    // across the K-loop, where they spill into VGPR lanes and cost the load halves v_readlane / s_nop pairs).
+    {
+      const int f3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, f4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
+      kernarg_words_t ka = (kernarg_words_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      unsigned kw[sizeof(GemmBf16Args) / 4];
+#pragma unroll
+      for (unsigned i = 0; i < sizeof(GemmBf16Args) / 4; ++i) kw[i] = ka[i];
+      GemmBf16Args ea;
+      __builtin_memcpy(&ea, kw, sizeof(GemmBf16Args));
+      nt256_wave_epilogue<MODE>(ea, acc, reinterpret_cast<float*>(smem + f3 * T2_BYTES + wave * 4096),
+                                    reinterpret_cast<float*>(smem + f4 * T2_BYTES + wave * 4096), m0, n0, wm, wn, lane PPSTAMP_PASS);
+    }
+    PP_BAR();
+#ifdef PP_LAB_STAMP
+    lab_acc[7] += 1;
+#endif
+    if (!has_next) break;
+    if (!leader) PP_BAR();                             // the follower idles through the leader's first L0
+    PPSTAMP(5)
+    tile = next; pA = pAn; pB = pBn; m0 = m0n; n0 = n0n;
+    if (dynamic) { next = -1; has_next = false; }
+    else {
+      next = next + G;
+      has_next = next < ntiles;
+      if (has_next) origin(next, pAn, pBn, m0n, n0n);
+    }
+  }
+#undef PP_BAR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cursors' last (unused) pieces
+#ifdef PP_LAB_STAMP2
+  if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 9; ++i) g_pp_stamp2[(blockIdx.x * 2 + wm) * 16 + i] = f_acc[i];
+#endif
+#ifdef PP_LAB_STAMP
+  lab_acc[8] = pp_now() - lab_t0;
+  lab_acc[9] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+  if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < PP_LAB_MAX_WG)
+    for (int i = 0; i < 10; ++i) g_pp_stamp[(blockIdx.x * 2 + wm) * 16 + i] = lab_acc[i];
+#endif
+  leave();
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN kernel: dW[n][k] += sum_m dY[m][n] X[m][k].  LDS tiles are [64 m][128 cols] (256-byte rows).
 constexpr int TN_BKM = 64;
 constexpr int TN_TILE_BYTES = TN_BKM * 128 * 2;    // 16 KiB
@@ -1134,6 +1695,17 @@ __global__ __launch_bounds__(256) void tn256_reduce_kernel(const float* __restri
 
 }  // namespace
 
+#ifdef PP_LAB_STAMP2
+extern "C" int meant_lab_pp_stamps2(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp_stamp2), bytes < sizeof(g_pp_stamp2) ? bytes : sizeof(g_pp_stamp2));
+}
+#endif
+#ifdef PP_LAB_STAMP
+extern "C" int meant_lab_pp_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp_stamp), bytes < sizeof(g_pp_stamp) ? bytes : sizeof(g_pp_stamp));
+}
+#endif
+
 // Scheduler slot of (current device, stream); nullptr when the table is full or the symbol cannot be resolved.
 // g_tile_sched is a __device__ array: every device has its own copy at its own address.
 static TileSched* tile_sched_for(hipStream_t stream) {
@@ -1180,6 +1752,12 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, true>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false, true>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_PLAIN, 2>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_RES, 2>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_GELU_PRE, 2>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_ROT, 2>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_EXT, 2>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_GENERIC, 2>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, false, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, true, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, false, true>), RING * T2_BYTES);
@@ -1237,11 +1815,35 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       // Tile counters: one slot per (device, stream).  Launches on one stream execute in order and a launch leaves its
       // slot zeroed (last workgroup out), so a slot is never shared by two launches in flight -- by construction, not by
       // distance.  A stream beyond the table's capacity gets the fixed walk (sched = nullptr).  Option nt_dynamic = 0 forces it.
-      const int dynmode = meant_opt(MEANT_OPT_NT_DYNAMIC);
+      const int dynmode0 = meant_opt(MEANT_OPT_NT_DYNAMIC);
+      const int dynmode = dynmode0;
       TileSched* sched = (dynmode != 0 && dynmode != 4 && grid <= 512) ? tile_sched_for(stream) : nullptr;
       meant_route_hit(a.rot_qa ? ROUTE_NT256S_ROT : ROUTE_NT256S);
       const dim3 g3((unsigned)grid), b3(512);
-      if (meant_opt(MEANT_OPT_NT_SPLIT) != 0) {          // DMA issue split in time between the two waves of a SIMD (see the kernel)
+      if (meant_opt(MEANT_OPT_NT_PP) != 0 && a.K >= 4 * BK) {   // ping-pong form: the two waves of a SIMD alternate between MFMA and load halves
+        const int ppopt = meant_opt(MEANT_OPT_NT_PP);
+        const int dynmode = dynmode0 | ((ppopt & 8) ? 0x100 : 0);   // lab, bit 3: staggered start
+        // the epilogue's options as a template parameter (see nt256_wave_epilogue): the combinations the models run get straight-line
+        // code, anything else the generic instantiation with run-time flags
+        const bool act = (a.epilogue & (MEANT_EPI_GELU | MEANT_EPI_SIGMOID)) != 0;
+        int emode = NTE_GENERIC;
+        if (a.rot_qa) emode = (!a.residual && !a.preact && !act) ? NTE_ROT : -1;
+        else if (ext) emode = NTE_EXT;
+        else if (!a.residual && !a.preact && !act) emode = NTE_PLAIN;
+        else if (a.residual && !a.preact && !act) emode = NTE_RES;
+        else if (!a.residual && a.preact && (a.epilogue & MEANT_EPI_GELU) && !(a.epilogue & MEANT_EPI_SIGMOID)) emode = NTE_GELU_PRE;
+        MEANT_REQUIRE(emode >= 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: rotary epilogue with residual / activation / preact");
+#define PP_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_bf16_nt256p_kernel<MODE_, 2>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode)
+        switch (emode) {
+          case NTE_PLAIN: PP_LAUNCH(NTE_PLAIN); break;
+          case NTE_RES: PP_LAUNCH(NTE_RES); break;
+          case NTE_GELU_PRE: PP_LAUNCH(NTE_GELU_PRE); break;
+          case NTE_ROT: PP_LAUNCH(NTE_ROT); break;
+          case NTE_EXT: PP_LAUNCH(NTE_EXT); break;
+          default: PP_LAUNCH(NTE_GENERIC); break;
+        }
+#undef PP_LAUNCH
+      } else if (meant_opt(MEANT_OPT_NT_SPLIT) != 0) {   // DMA issue split in time between the two waves of a SIMD (see the kernel)
         if (a.rot_qa) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<128, true>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
         else if (ext) hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<128, false, true>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);
         else hipLaunchKernelGGL((gemm_bf16_nt256s_kernel<128, false>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode);

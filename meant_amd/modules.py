@@ -288,8 +288,10 @@ class visionEncoder(nn.Module):
         self.encode = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), atten, RMSNorm(dim), Linear(dim, dim)])
         self.encode2 = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), nn.GELU(), RMSNorm(dim), Linear(dim, dim)])
 
-    def forward(self, input, pool: bool = False):
-        """pool=True: return (h, res) instead of encode2[-1](h) + res, for ops.pool_linear_cat"""
+    def forward(self, input, pool: bool = False, fold=None):
+        """pool=True: return (h, res) instead of encode2[-1](h) + res, for ops.pool_linear_cat.
+        fold: the stack's RMSNorm-into-Linear decision (an explicit argument so that a recomputation under
+        torch.utils.checkpoint repeats the forward's path); None = by ops.fold_wanted()"""
         e, e2 = self.encode, self.encode2
         n, res = ops.rmsnorm_fork(input, e[0].scale, e[0].eps)      # residual gradient is folded into this norm's backward
         if COMPOSE_PRE_LINEAR and e[1].bias is not None:
@@ -298,7 +300,7 @@ class visionEncoder(nn.Module):
             h = e[2](e[1](n))
         h = e[3](h)
         x1 = e[4](h, residual=res)
-        fold = ops.norm_linear_ok(x1, e2[1].weight)                   # encode2[0] rides encode2[1]'s GEMM as a per-row factor
+        fold = ops.norm_linear_ok(x1, e2[1].weight, fold)                 # encode2[0] rides encode2[1]'s GEMM as a per-row factor
         if pool and ops.pooled_norm_ok(x1, x1.shape[1]):             # the two norms beside the mean-pool emit the means themselves
             if fold:
                 return ops.norm_linear_gelu_norm_pooled(x1, e2[0].scale, e2[0].eps, e2[1].weight, e2[1].bias, e2[3].scale, e2[3].eps)
@@ -326,8 +328,8 @@ class languageEncoder(nn.Module):
         self.encode = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), att, RMSNorm(dim), nn.Dropout(dropout), Linear(dim, dim)])
         self.encode2 = nn.ModuleList([RMSNorm(dim), Linear(dim, dim), nn.GELU(), RMSNorm(dim), nn.Dropout(), Linear(dim, dim)])
 
-    def forward(self, input, attention_mask=None, pool: bool = False):
-        """pool=True: return (h, res) instead of encode2[-1](h) + res, for ops.pool_linear_cat"""
+    def forward(self, input, attention_mask=None, pool: bool = False, fold=None):
+        """pool=True: return (h, res) instead of encode2[-1](h) + res, for ops.pool_linear_cat; fold: as visionEncoder.forward"""
         e, e2 = self.encode, self.encode2
         p1 = e[4].p if self.training else 0.0
         p2 = e2[4].p if self.training else 0.0
@@ -338,7 +340,7 @@ class languageEncoder(nn.Module):
             h = e[2](e[1](n), attention_mask)
         h = e[3](h, drop_p=p1, seed=_seed() if p1 > 0 else 0)
         x1 = e[5](h, residual=res)
-        fold = ops.norm_linear_ok(x1, e2[1].weight)                   # encode2[0] rides encode2[1]'s GEMM as a per-row factor
+        fold = ops.norm_linear_ok(x1, e2[1].weight, fold)                 # encode2[0] rides encode2[1]'s GEMM as a per-row factor
         seed2 = _seed() if p2 > 0 else 0
         if pool and ops.pooled_norm_ok(x1, x1.shape[1]):             # the two norms beside the mean-pool emit the means themselves
             if fold:
@@ -428,14 +430,16 @@ def _run_stack(encoders, x, *args, checkpoint=False):
     """all encoder layers of one stack; returns either the token tensor, or -- with POOL_LAST_LINEAR -- the
     (h, res, weight, bias) part that ops.pool_linear_cat pools.  checkpoint: bool, or the number of leading layers to recompute"""
     n = len(encoders)
-    ops.set_stack_hint(n, x.numel() // x.shape[-1], x.shape[-1])      # big stacks fold their norms into the consumer Linears (ops.fold_wanted)
+    # big stacks fold their norms into the consumer Linears.  Decided ONCE per stack and passed down as an argument: the layers run
+    # under torch.utils.checkpoint are re-run in backward, after the OTHER stack may have left a different process-wide hint
+    fold = ops.stack_fold(n, x.numel() // x.shape[-1], x.shape[-1])
     for i, enc in enumerate(encoders):
         ck = checkpoint if isinstance(checkpoint, bool) else i < checkpoint
         last = enc.encode2[-1]
         if POOL_LAST_LINEAR and i == n - 1 and isinstance(last, Linear):
-            h, res = _run_encoder(enc, x, *args, checkpoint=ck, pool=True)
+            h, res = _run_encoder(enc, x, *args, checkpoint=ck, pool=True, fold=fold)
             return (h, res, last.weight, last.bias)
-        x = _run_encoder(enc, x, *args, checkpoint=ck)
+        x = _run_encoder(enc, x, *args, checkpoint=ck, fold=fold)
     return x
 
 
@@ -689,9 +693,9 @@ class meant_language_pretrainer(nn.Module):
     def _encode(self, words, attention_mask):
         dt = resolve_compute_dtype(self, None)
         x = _embed(self.embedding, words, dt)
-        ops.set_stack_hint(len(self.languageEncoders), x.numel() // x.shape[-1], x.shape[-1])
+        fold = ops.stack_fold(len(self.languageEncoders), x.numel() // x.shape[-1], x.shape[-1])
         for enc in self.languageEncoders:
-            x = enc(x, attention_mask=attention_mask)
+            x = enc(x, attention_mask=attention_mask, fold=fold)
         return x
 
     def _head_features(self, x):
@@ -741,9 +745,9 @@ class meant_vision_pretrainer(nn.Module):
     def forward(self, images):
         dt = resolve_compute_dtype(self, images)
         x = self.patchEmbed(images, dt)                                  # [B, n, d]
-        ops.set_stack_hint(len(self.visionEncoders), x.numel() // x.shape[-1], x.shape[-1])
+        fold = ops.stack_fold(len(self.visionEncoders), x.numel() // x.shape[-1], x.shape[-1])
         for enc in self.visionEncoders:
-            x = enc(x)
+            x = enc(x, fold=fold)
         b, n, c = x.shape
         hw = math.floor(n ** 0.5)
         dec = self.decoder

@@ -433,7 +433,9 @@ _stack_bytes = 0
 
 
 def set_stack_hint(layers: int, tokens: int, d: int) -> None:
-    """called by the model classes before they run a stack of encoder layers: what one bf16 [tokens, d] tensor per layer adds up to"""
+    """what one bf16 [tokens, d] tensor per layer of a stack adds up to.  Only a DEFAULT for encoder layers that are called on
+    their own: the model classes decide per stack (stack_fold) and hand the decision to every layer as an argument, so that a
+    layer recomputed under torch.utils.checkpoint takes the path its forward took whatever ran in between."""
     global _stack_bytes
     _stack_bytes = int(layers) * int(tokens) * int(d) * 2
 
@@ -442,14 +444,22 @@ def fold_wanted() -> bool:
     return bool(FUSE_NORM_LINEAR) if FUSE_NORM_LINEAR is not None else _stack_bytes >= FOLD_AUTO_BYTES
 
 
+def stack_fold(layers: int, tokens: int, d: int) -> bool:
+    """the fold decision of ONE stack of encoder layers (also leaves the hint for layers called outside a stack)"""
+    set_stack_hint(layers, tokens, d)
+    return fold_wanted()
+
+
 fold_calls = [0, 0]                                                       # [separate, folded] decisions taken so far (bench.py reports them)
 
 
-def norm_linear_ok(x, weight) -> bool:
-    """shapes the folded path covers: bf16 tier, K a multiple of 64, a packed norm width, 16-byte aligned rows"""
+def norm_linear_ok(x, weight, wanted=None) -> bool:
+    """shapes the folded path covers: bf16 tier, K a multiple of 64, a packed norm width, 16-byte aligned rows.
+    wanted: the stack's decision (modules._run_stack); None = by the process-wide hint"""
     d = x.shape[-1]
     rows = x.numel() // d
-    ok = bool(fold_wanted() and x.dtype == torch.bfloat16 and x.is_cuda and d % 64 == 0 and weight.shape[1] == d
+    want = fold_wanted() if wanted is None else bool(wanted)
+    ok = bool(want and x.dtype == torch.bfloat16 and x.is_cuda and d % 64 == 0 and weight.shape[1] == d
               and weight.shape[0] % 8 == 0 and rows > 0 and lib.meant_rmsnorm_pooled_ok(rows, d, rows))
     fold_calls[ok] += 1
     return ok

@@ -180,3 +180,39 @@ def test_folded_and_separate_paths_agree_on_the_models(dev, monkeypatch):
     big = max(g.norm().item() for g in res[0][1].values())
     for k, g0 in res[0][1].items():
         assert (g0 - res[1][1][k]).norm().item() <= tol["gnorm"] * max(g0.norm().item(), 2e-2 * big), k
+
+
+def test_checkpointed_layers_repeat_their_stacks_fold_decision(dev, monkeypatch):
+    """activation checkpointing with the AUTO fold rule set so that the text stack folds and the vision stack does not (ADVICE r3:
+    the decision used to be a process-wide hint read inside each layer's forward, and a recomputed vision layer saw the hint the
+    text stack had left).  The fold is now decided once per stack and handed to the layers as an argument: the checkpointed run
+    must reproduce the plain run's outputs and gradients, and both must take one folded and one separate path per layer pair."""
+    import meant_amd as M
+    from meant_amd import ops
+    torch.manual_seed(9)
+    m = M.meant(128, 128, 4, 32, 64, 16, 2, 3, torch.nn.Embedding(50, 128), num_heads=2, num_encoders=2, channels=4).to(dev).train()
+    m.compute_dtype = torch.bfloat16
+    rs = np.random.RandomState(8)
+    ids = torch.from_numpy(rs.randint(0, 50, (3, 2, 24))).to(dev)
+    img = torch.from_numpy(rs.standard_normal((3, 2, 4, 32, 64)).astype("float32")).to(dev)
+    mask = torch.ones(3, 2, 24, device=dev)
+    text_bytes = 2 * (3 * 2 * 24) * 128 * 2                  # layers x tokens x d x 2 B
+    vision_bytes = 2 * (3 * 2 * 8) * 128 * 2
+    assert vision_bytes < text_bytes
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", None)
+    monkeypatch.setattr(ops, "FOLD_AUTO_BYTES", text_bytes)  # text stack: fold; vision stack: separate norms
+    res = []
+    for ck, recomputed in ((False, 0), (True, 2), (1, 1)):   # 1: only the first layer of each stack is recomputed
+        m.activation_checkpointing = ck
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(123)
+        before = list(ops.fold_calls)
+        out = m(ids, img, mask)
+        (out * torch.arange(1, out.numel() + 1, device=dev).view_as(out)).sum().backward()
+        took = [ops.fold_calls[0] - before[0], ops.fold_calls[1] - before[1]]
+        assert took == [2 + recomputed, 2 + recomputed], (ck, took)     # per stack: 2 layers forward (+ the recomputed ones)
+        res.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for k, g0 in res[0][1].items():
+            assert (g0 - other[1][k]).abs().max().item() <= 1e-5 * max(1.0, g0.abs().max().item()), k
