@@ -50,7 +50,7 @@ int meant_raise_dyn_lds(const void* kernel, int bytes);
   } while (0)
 
 enum meant_option_id {
-  MEANT_OPT_NT_STREAM = 0, MEANT_OPT_NT_DYNAMIC, MEANT_OPT_DETERMINISTIC, MEANT_OPT_NT_GRID_CAP, MEANT_OPT_ATTN_SHORT, MEANT_OPT_NT_RAGGED, MEANT_OPT_NT_SPLIT, MEANT_OPT_ATTN_BWD1, MEANT_OPT_NT_PP, MEANT_OPT_COUNT
+  MEANT_OPT_NT_STREAM = 0, MEANT_OPT_NT_DYNAMIC, MEANT_OPT_DETERMINISTIC, MEANT_OPT_NT_GRID_CAP, MEANT_OPT_ATTN_SHORT, MEANT_OPT_NT_RAGGED, MEANT_OPT_NT_SPLIT, MEANT_OPT_ATTN_BWD1, MEANT_OPT_NT_PP, MEANT_OPT_TN_PP, MEANT_OPT_COUNT
 };
 int meant_opt(int id);
 

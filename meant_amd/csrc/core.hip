@@ -83,6 +83,7 @@ const OptionDef k_options[MEANT_OPT_COUNT] = {
     {"nt_split", "MEANT_NT_SPLIT", 0},             // 1: streaming GEMM: waves 0-3 issue the B tiles at the top of a K-step, waves 4-7 the A tiles after their MFMAs
     {"attn_bwd1", "MEANT_ATTN_BWD1", 1},           // 0: attention backward always as two passes (dQ, then dK / dV) instead of the single-pass kernel where it applies
     {"nt_pp", "MEANT_NT_PP", 1},                   // 0: streaming GEMM in its lock-step form (gemm_bf16_nt256s_kernel) instead of the ping-pong kernel; bit 3 (lab): staggered start
+    {"tn_pp", "MEANT_TN_PP", 1},                   // 0: 256 x 256 dW kernel in its lock-step form (gemm_bf16_tn256_kernel) instead of the ping-pong kernel
 };
 std::atomic<int> g_opt[MEANT_OPT_COUNT];
 std::once_flag g_opt_once;

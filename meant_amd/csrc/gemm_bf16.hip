@@ -1063,6 +1063,22 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds) {   // sbase, lds: wave-uniform
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
+// the four pieces (1 KiB each, consecutive in LDS) a wave owns of one tile.  PP_DMA_IMM: ONE M0 write for the group; the
+// instruction's immediate offset moves source and destination alike, so piece p's lane offset is built as v[p] - 1024 p (the
+// launch code adds 3072 to every v[] and subtracts it from the base: the 32-bit lane offset is unsigned)
+#ifndef PP_DMA_IMM
+#define PP_DMA_IMM 1
+#endif
+__device__ __forceinline__ void glds16_x4(const void* sbase, const unsigned (&v)[4], unsigned lds) {
+#if PP_DMA_IMM
+  asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+               "global_load_lds_dwordx4 %2, %4 offset:2048\n\tglobal_load_lds_dwordx4 %3, %4 offset:3072"
+               ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"((const char*)sbase - 3072), "s"(lds) : "memory");
+#else
+#pragma unroll
+  for (int p = 0; p < 4; ++p) glds16_s(sbase, v[p], lds + p * 1024);
+#endif
+}
 typedef const __attribute__((address_space(4))) unsigned* kernarg_words_t;
 static_assert(sizeof(GemmBf16Args) % 4 == 0, "kernarg copy by words");
 
@@ -1086,9 +1102,8 @@ __device__ unsigned long long g_pp_stamp2[256 * 2 * 16];
 #define PP2_M_BEGIN(i)
 #define PP2_M_END(i)
 #endif
-template <int MODE, int P>
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a, int ntm, int ntn, TileSched* __restrict__ sched, int mode) {
-  static_assert(P == 2 || P == 4, "phases per K-step");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -1117,8 +1132,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
   unsigned vA[4], vB[4];                               // byte offsets of this lane's 16 bytes of piece p from the tile's origin
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    vA[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.lda + (c0 ^ ((p & 1) << 2)) * 8) * 2);
-    vB[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.ldb + (c0 ^ ((p & 1) << 2)) * 8) * 2);
+    vA[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.lda + (c0 ^ ((p & 1) << 2)) * 8) * 2) + (PP_DMA_IMM ? 3072 - 1024 * p : 0);
+    vB[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.ldb + (c0 ^ ((p & 1) << 2)) * 8) * 2) + (PP_DMA_IMM ? 3072 - 1024 * p : 0);
   }
   const unsigned lds0 = lds_addr(smem) + wave * 4096;  // this wave's first piece inside slot 0
   auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
@@ -1151,12 +1166,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
   // prologue: A_0, B_0, A_1 (four pieces per wave and tile); the first two must have landed
-#pragma unroll
-  for (int p = 0; p < 4; ++p) glds16_s(pA, vA[p], lds0 + p * 1024);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) glds16_s(pB, vB[p], lds0 + T2_BYTES + p * 1024);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) glds16_s(pA + BK, vA[p], lds0 + 2 * T2_BYTES + p * 1024);
+  glds16_x4(pA, vA, lds0);
+  glds16_x4(pB, vB, lds0 + T2_BYTES);
+  glds16_x4(pA + BK, vA, lds0 + 2 * T2_BYTES);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1190,8 +1202,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
   const unsigned fo0 = (unsigned)(frow * 128 + ((fkg ^ (frow >> 1)) << 4));
   const unsigned foA[2] = {fo0 + wm * 16384, (fo0 ^ 64u) + wm * 16384};
   const unsigned foB[2] = {fo0 + wn * 8192, (fo0 ^ 64u) + wn * 8192};
-  int kspecial = dynamic ? 3 : -1;
-  int sA = 0;                                          // ring slot of the current step's A tile; B sits in the next one
+  // ---- per-step scalars, software-pipelined: the values of step n+1 are computed in step n's LAST load half (beside the partner
+  // group's MFMAs) and pinned in front of its barrier, so that nothing but the moves sits between a step's last barrier and the next
+  // step's first DMA piece.  ring slot of A_n: sA; B_n sits in the next one, B_{n+1} goes to sA + 3, A_{n+2} to sA + 4 (mod 5).
+  int kspecial = dynamic ? 2 : -1;                     // the draw: request in step 2, published behind it, read in step 4
+  int sA = 0;
+  unsigned aoff = 0, boff = T2_BYTES, dB = lds0 + 3 * T2_BYTES, dA = lds0 + 4 * T2_BYTES;
   for (;;) {
     f32x4 acc[8][4];
 #pragma unroll
@@ -1200,26 +1216,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
-      const int sB = sA + 1 == RING ? 0 : sA + 1;
-      const int s3 = sA + 3 >= RING ? sA + 3 - RING : sA + 3, s4 = sA + 4 >= RING ? sA + 4 - RING : sA + 4;
       // tile draw, part 1 (see TileSched): requests only; they are older than this step's DMA pieces, so the counted wait that
       // ends the step covers them.  hipcc does not know these registers are in flight (tests/test_isa_guards.py checks the ISA).
       // Everything about the draw sits behind ONE scalar test per step: the load halves hide under the partner's MFMAs only while
       // they stay short (a wave issues an instruction every ~4-5 cycles).
       unsigned mail = 0, ticket = 0;
-      const bool special = kt == kspecial;              // kspecial: 3, then 5, then never (-1 without the dynamic hand-out)
+      const bool special = kt == kspecial;              // kspecial: 2, then 4, then never (-1 without the dynamic hand-out)
       bool drawer = false;
       const bool own = !((mode & 0xff) == 3 && xcd != 0);
       if (special) {
-        if (kt == 5) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(mail) : "v"(mailbox) : "memory");
+        if (kt == 4) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(mail) : "v"(mailbox) : "memory");
         else {
           drawer = wave == 4 && lane == 0;
           if (drawer && own) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(&sched->next[xcd]), "v"(1u) : "memory");
         }
       }
 
-      const unsigned aoff = (unsigned)sA * T2_BYTES, boff = (unsigned)sB * T2_BYTES;
-      const unsigned dB = lds0 + (unsigned)s3 * T2_BYTES, dA = lds0 + (unsigned)s4 * T2_BYTES;
       bf16x8 aq[2][4], bq[2][4];
       auto ldA = [&](int ih, int ks, bf16x8 (&d)[4]) {
 #pragma unroll
@@ -1237,76 +1249,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
             acc[ih * 4 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[ii], acc[ih * 4 + ii][j], 0, 0, 0);   // swapped: acc = C^T tile
       };
       auto wait_step = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
-      if (P == 2) {
-        // ---- phase 0: rows 0..63 of the wave's block, both k-halves ----------------------------------------------------
-        PP2_BEGIN()
-#pragma unroll
-        for (int p = 0; p < 4; ++p) glds16_s(qB, vB[p], dB + p * 1024);
-        ldB(0, bq[0]); ldB(1, bq[1]);
-        ldA(0, 0, aq[0]); ldA(0, 1, aq[1]);
-        PP2_L_END()
-        PP_BAR();
-        PP2_M_BEGIN(0)
-        __builtin_amdgcn_s_setprio(1);
-        mm(0, aq[0], bq[0]); mm(0, aq[1], bq[1]);
-        __builtin_amdgcn_s_setprio(0);
-        PP2_M_END(2)
-        PP_BAR();
-        // ---- phase 1: rows 64..127 ------------------------------------------------------------------------------------
-        PP2_BEGIN2(3)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) glds16_s(qA, vA[p], dA + p * 1024);
-        ldA(1, 0, aq[0]); ldA(1, 1, aq[1]);
-        PP2_L_END()
-        __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 0: rows 0..63 of the wave's block, both k-halves ------------------------------------------------------
+      PP2_BEGIN()
+      glds16_x4(qB, vB, dB);
+      ldB(0, bq[0]); ldB(1, bq[1]);
+      ldA(0, 0, aq[0]); ldA(0, 1, aq[1]);
+      PP2_L_END()
+      PP_BAR();
+      PP2_M_BEGIN(0)
+      __builtin_amdgcn_s_setprio(1);
+      mm(0, aq[0], bq[0]); mm(0, aq[1], bq[1]);
+      __builtin_amdgcn_s_setprio(0);
+      PP2_M_END(2)
+      PP_BAR();
+      // ---- phase 1: rows 64..127 --------------------------------------------------------------------------------------
+      PP2_BEGIN2(3)
+      glds16_x4(qA, vA, dA);
+      ldA(1, 0, aq[0]); ldA(1, 1, aq[1]);
+      // the next step's scalars (see above).  Cursors: one K-block on, or into the next tile when the step they feed is one (B: step
+      // kt + 2 of this tile does not exist; A: step kt + 3).  pAn / pBn are final by then: the draw is read behind step 4 and
+      // the dynamic hand-out needs nk >= 8.
+      int n_sA = sA + 2 >= RING ? sA + 2 - RING : sA + 2;
+      const int n_sB = n_sA + 1 == RING ? 0 : n_sA + 1;
+      const int n_s3 = n_sA + 3 >= RING ? n_sA + 3 - RING : n_sA + 3, n_s4 = n_sA + 4 >= RING ? n_sA + 4 - RING : n_sA + 4;
+      unsigned n_aoff = (unsigned)n_sA * T2_BYTES, n_boff = (unsigned)n_sB * T2_BYTES;
+      unsigned n_dB = lds0 + (unsigned)n_s3 * T2_BYTES, n_dA = lds0 + (unsigned)n_s4 * T2_BYTES;
+      const bf16* n_qB = kt + 2 == nk ? pBn : qB + BK;
+      const bf16* n_qA = kt + 3 == nk ? pAn : qA + BK;
+      asm volatile("" : "+s"(n_sA), "+s"(n_aoff), "+s"(n_boff), "+s"(n_dB), "+s"(n_dA), "+s"(n_qB), "+s"(n_qA));
+      PP2_L_END()
+      __builtin_amdgcn_sched_barrier(0);
 #ifdef PP_LAB_STAMP
-        if (!leader) { if (kt) PPSTAMP(0) else PPSTAMP(1) }
+      if (!leader) { if (kt) PPSTAMP(0) else PPSTAMP(1) }
 #endif
-        if (!leader) wait_step();                      // follower: its pieces of the next step must be in before the leader's L0
+      if (!leader) wait_step();                        // follower: its pieces of the next step must be in before the leader's L0
 #ifdef PP_LAB_STAMP
-        if (!leader) PPSTAMP(2)
+      if (!leader) PPSTAMP(2)
 #endif
-        PP_BAR();
-        PP2_M_BEGIN(4)
-        __builtin_amdgcn_s_setprio(1);
-        mm(1, aq[0], bq[0]); mm(1, aq[1], bq[1]);
-        __builtin_amdgcn_s_setprio(0);
-        PP2_M_END(6)
-      } else {
-        // ---- phase 0: rows 0..63, k 0..31 ------------------------------------------------------------------------------
-        glds16_s(qB, vB[0], dB); glds16_s(qB, vB[1], dB + 1024);
-        ldB(0, bq[0]); ldA(0, 0, aq[0]);
-        PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
-        mm(0, aq[0], bq[0]);
-        __builtin_amdgcn_s_setprio(0);
-        PP_BAR();
-        // ---- phase 1: rows 64..127, k 0..31 ----------------------------------------------------------------------------
-        glds16_s(qB, vB[2], dB + 2048); glds16_s(qB, vB[3], dB + 3072);
-        ldA(1, 0, aq[1]);
-        PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
-        mm(1, aq[1], bq[0]);
-        __builtin_amdgcn_s_setprio(0);
-        PP_BAR();
-        // ---- phase 2: rows 0..63, k 32..63 -----------------------------------------------------------------------------
-        glds16_s(qA, vA[0], dA); glds16_s(qA, vA[1], dA + 1024);
-        ldB(1, bq[1]); ldA(0, 1, aq[0]);
-        PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
-        mm(0, aq[0], bq[1]);
-        __builtin_amdgcn_s_setprio(0);
-        PP_BAR();
-        // ---- phase 3: rows 64..127, k 32..63 ---------------------------------------------------------------------------
-        glds16_s(qA, vA[2], dA + 2048); glds16_s(qA, vA[3], dA + 3072);
-        ldA(1, 1, aq[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!leader) wait_step();
-        PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
-        mm(1, aq[1], bq[1]);
-        __builtin_amdgcn_s_setprio(0);
-      }
+      PP_BAR();
+      PP2_M_BEGIN(4)
+      __builtin_amdgcn_s_setprio(1);
+      mm(1, aq[0], bq[0]); mm(1, aq[1], bq[1]);
+      __builtin_amdgcn_s_setprio(0);
+      PP2_M_END(6)
       __builtin_amdgcn_sched_barrier(0);
 #ifdef PP_LAB_STAMP
       if (leader) { if (kt) PPSTAMP(0) else PPSTAMP(1) }
@@ -1321,11 +1306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
 #endif
       // the follower's last MFMAs of a tile and its epilogue share one interval (see the header)
       if (leader || kt + 1 < nk) PP_BAR();
-      // ---- bookkeeping of the step, BEHIND its last barrier: it runs beside the partner group's MFMA half -------------------------
-      // cursors for the next step: one K-block on, or into the next tile when the step they feed is one (B: step kt + 2 of this
-      // tile does not exist; A: step kt + 3)
-      qB = kt + 2 == nk ? pBn : qB + BK;
-      qA = kt + 3 == nk ? pAn : qA + BK;
+      sA = n_sA; aoff = n_aoff; boff = n_boff; dB = n_dB; dA = n_dA; qB = n_qB; qA = n_qA;
       if (special) {
         asm volatile("" : "+v"(mail), "+v"(ticket) : : "memory");
         // tile draw, part 2: the answers are here (the step's counted wait covered them)
@@ -1345,17 +1326,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
           const unsigned pub = id < ntiles ? (unsigned)id : 0xffffffffu;
           asm volatile("global_store_dword %0, %1, off sc1" ::"v"(mailbox), "v"(pub) : "memory");
         }
-        if (kt == 5) {
+        if (kt == 4) {
           const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)mail);
           next = (mode & 0xff) == 2 ? (tile + G < ntiles ? tile + G : -1) : (int)got;
           has_next = next >= 0;
           if (has_next) origin(next, pAn, pBn, m0n, n0n);
         }
-        kspecial = kt == 3 ? 5 : -1;
+        kspecial = kt == 2 ? 4 : -1;
       }
-      sA = sA + 2 >= RING ? sA + 2 - RING : sA + 2;
     }
-    kspecial = dynamic ? 3 : -1;
+    kspecial = dynamic ? 2 : -1;
 
     // ---- epilogue: the two slots of the tile's last step are free; each wave's patches lie inside rows only its own group read.
     // Its arguments come fresh from the kernarg segment (the pointer is laundered so that hipcc cannot keep them in SGPRs
@@ -1670,6 +1650,200 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(const bf16* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dW kernel, PING-PONG form (round 4): the structure of gemm_bf16_nt256p_kernel on the tiles, fragments and epilogue of
+// gemm_bf16_tn256_kernel.  Output tile 256 (n) x 256 (k), waves 2 (n) x 4 (k), 128 x 64 per wave in 4 x 2 accumulators of
+// v_mfma_f32_32x32x16_bf16; a STEP is 64 token rows ([64 m][256] tiles of dY and X, 512-byte rows, transposed fragment reads), a
+// phase is one half of them (k-steps 0-1: token rows 0..31; k-steps 2-3: rows 32..63): 24 ds_read_b64_tr_b16 + 4 LDS-DMA pieces in
+// its LOAD half, 16 MFMAs (512 cycles) in its MFMA half.  The leader (waves 0-3: n rows 0..127) and the follower (waves 4-7) run one
+// barrier interval apart, so one wave of every SIMD is always in an MFMA half.
+// Ring of five 32 KiB slots: dY_t, X_t, dY_t+1, X_t+1 (landing during step t), dY_t+2 (landing).  Every wave reads all 64 token rows of
+// both tiles (its own columns), so a slot of step t-1 is refilled by halves: token rows 0..31 were last read in the follower's first
+// load half of step t-1 and are refilled by waves 0-3 (pieces 4w + p = rows 8w + 2p ..) from the leader's L0 of step t on; rows
+// 32..63 were last read in the follower's second load half and are refilled by waves 4-7, whose L0 of step t comes behind the
+// barrier that follows those reads' completion.
+// Steps past the end of the split keep prefetching its last rows (never read): no branch in the loop distinguishes them.
+template <bool DET>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn256p_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
+                                                                   int64_t ldx, float* __restrict__ dW, float* __restrict__ dbias,
+                                                                   int64_t M, int64_t N, int64_t K, int ntn, int ntk,
+                                                                   int64_t rows_per_split, float* __restrict__ part,
+                                                                   float* __restrict__ pbias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 2, wk = wave & 3;
+  const bool leader = wn == 0;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // (integer division runs on the VALU: say explicitly that the quotients are wave-uniform, they end up as SGPR operands of asm)
+  const int tile = __builtin_amdgcn_readfirstlane(bid % (ntn * ntk));
+  const int split = __builtin_amdgcn_readfirstlane(bid / (ntn * ntk));
+  const int tn = tile / ntk, tk = tile - tn * ntk;
+  const int64_t n0 = (int64_t)tn * 256, k0 = (int64_t)tk * 256;
+  const int64_t mbeg = (int64_t)split * rows_per_split;
+  const int64_t mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  if (mbeg >= mend) return;
+  const int nt = __builtin_amdgcn_readfirstlane((int)((mend - mbeg + TN_BKM - 1) / TN_BKM));
+  const bool do_bias = dbias != nullptr;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = tn256_lane_off(wn * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = tn256_lane_off(wk * 64 + j * 32, lane);
+
+  // DMA: piece q (1 KiB = 2 token rows of 512 B) of a 32-piece tile; wave w owns pieces 4w + p, i.e. rows 8w + 2p + (lane >> 5).
+  // 16-byte chunk c of row r sits at slot c ^ (4 (r & 3)), and r & 3 = 2 (p & 1) + (lane >> 5).
+  unsigned vY[4], vX[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = 8 * wave + 2 * p + (lane >> 5);
+    const int c = (lane & 31) ^ ((r & 3) << 2);
+    vY[p] = (unsigned)((r * lddy + c * 8) * 2) + (PP_DMA_IMM ? 3072 - 1024 * p : 0);
+    vX[p] = (unsigned)((r * ldx + c * 8) * 2) + (PP_DMA_IMM ? 3072 - 1024 * p : 0);
+  }
+  const unsigned lds0 = lds_addr(smem) + wave * 4096;
+  const bf16* pY = dY + mbeg * lddy + n0;
+  const bf16* pX = X + mbeg * ldx + k0;
+  const int64_t stepY = (int64_t)TN_BKM * lddy, stepX = (int64_t)TN_BKM * ldx;
+  // prologue: dY_0, X_0, dY_1 (the last step's rows again when the split has a single step)
+  const bf16* qY = nt > 1 ? pY + stepY : pY;           // cursor of the dY pieces: two steps ahead of the step that issues them
+  glds16_x4(pY, vY, lds0);
+  glds16_x4(pX, vX, lds0 + T2_BYTES);
+  glds16_x4(qY, vY, lds0 + 2 * T2_BYTES);
+  const bf16* qX = nt > 1 ? pX + stepX : pX;           // cursor of the X pieces: one step ahead
+  qY = nt > 2 ? qY + stepY : qY;
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (!leader) {                                       // the follower's one-interval lag
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+#define PP_BAR()                          \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+  const unsigned sbase = lds_addr(smem);
+  int sA = 0;
+  unsigned ya = sbase, xa = sbase + T2_BYTES, dXs = lds0 + 3 * T2_BYTES, dYs = lds0 + 4 * T2_BYTES;
+  for (int t = 0; t < nt; ++t) {
+    const bool bias_step = do_bias && (t % ntk) == tk;
+    u32x2 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
+    // the 24 transposed reads of one phase (k-steps 2 ph and 2 ph + 1), inline asm: nothing may touch the destinations before the
+    // lgkmcnt(0) at the top of the MFMA half (tools/isa_inflight_check.py)
+    auto frag_reads = [&](auto PH) {
+      constexpr int ph = decltype(PH)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        alo[0][i] = lds_read_tr16<(2 * ph) * 8192>(ya + aoff[i]);
+        ahi[0][i] = lds_read_tr16<(2 * ph) * 8192 + 2048>(ya + aoff[i]);
+        alo[1][i] = lds_read_tr16<(2 * ph + 1) * 8192>(ya + aoff[i]);
+        ahi[1][i] = lds_read_tr16<(2 * ph + 1) * 8192 + 2048>(ya + aoff[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        blo[0][j] = lds_read_tr16<(2 * ph) * 8192>(xa + boff[j]);
+        bhi[0][j] = lds_read_tr16<(2 * ph) * 8192 + 2048>(xa + boff[j]);
+        blo[1][j] = lds_read_tr16<(2 * ph + 1) * 8192>(xa + boff[j]);
+        bhi[1][j] = lds_read_tr16<(2 * ph + 1) * 8192 + 2048>(xa + boff[j]);
+      }
+    };
+    auto mfma_half = [&](int ph) {
+      lds_wait_all();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 af[4], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = pack_tr(alo[s2][i], ahi[s2][i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[j] = pack_tr(blo[s2][j], bhi[s2][j]);
+        // fused dbias: column sums of dY from the A fragments, dealt out over the k-tiles' workgroups (step t belongs to the one
+        // with tk == t mod ntk) and over a workgroup's waves (k-sub-step ks belongs to wave wk == ks).  The adds of fragment i sit
+        // BEHIND its two MFMAs (which took their operands at issue) and in front of the next pair: an MFMA holds the matrix pipe for
+        // 32 cycles and the issue port for 8 of them, so a dozen vector instructions per pair ride along
+        const bool bias_now = bias_step && 2 * ph + s2 == wk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (bias_now) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[i] += (float)af[i][e];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // ---- phase 0: token rows 0..31 ----------------------------------------------------------------------------------------
+    glds16_x4(qX, vX, dXs);
+    frag_reads(std::integral_constant<int, 0>{});
+    PP_BAR();
+    mfma_half(0);
+    PP_BAR();
+    // ---- phase 1: token rows 32..63 ---------------------------------------------------------------------------------------
+    glds16_x4(qY, vY, dYs);
+    frag_reads(std::integral_constant<int, 1>{});
+    // the next step's scalars, computed here (beside the partner group's MFMAs) and pinned in front of the barrier
+    int n_sA = sA + 2 >= RING ? sA + 2 - RING : sA + 2;
+    const int n_sB = n_sA + 1 == RING ? 0 : n_sA + 1;
+    const int n_s3 = n_sA + 3 >= RING ? n_sA + 3 - RING : n_sA + 3, n_s4 = n_sA + 4 >= RING ? n_sA + 4 - RING : n_sA + 4;
+    unsigned n_ya = sbase + (unsigned)n_sA * T2_BYTES, n_xa = sbase + (unsigned)n_sB * T2_BYTES;
+    unsigned n_dX = lds0 + (unsigned)n_s3 * T2_BYTES, n_dY = lds0 + (unsigned)n_s4 * T2_BYTES;
+    const bf16* n_qX = t + 2 < nt ? qX + stepX : qX;
+    const bf16* n_qY = t + 3 < nt ? qY + stepY : qY;
+    asm volatile("" : "+s"(n_sA), "+s"(n_ya), "+s"(n_xa), "+s"(n_dX), "+s"(n_dY), "+s"(n_qX), "+s"(n_qY));
+    __builtin_amdgcn_sched_barrier(0);
+    if (!leader) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // follower: its pieces of the next step must be in before the leader's L0
+    PP_BAR();
+    mfma_half(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (leader) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    PP_BAR();
+    sA = n_sA; ya = n_ya; xa = n_xa; dXs = n_dX; dYs = n_dY; qX = n_qX; qY = n_qY;
+  }
+  if (leader) PP_BAR();                                // pairs with the barrier behind the follower's last MFMA half
+#undef PP_BAR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cursors' last (unused) pieces
+  float* ptile = DET ? part + ((int64_t)split * (ntn * ntk) + tile) * 65536 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kl = wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nl = wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (DET) ptile[nl * 256 + kl] = acc[i][j][e];
+        else atomicAdd(dW + (n0 + nl) * K + k0 + kl, acc[i][j][e]);
+      }
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s2 = csum[i] + __shfl_xor(csum[i], 32, 64);
+      if (lane < 32) {
+        const int64_t n = n0 + wn * 128 + i * 32 + lane;
+        if (DET) pbias[(((int64_t)split * ntk + tk) * 4 + wk) * N + n] = s2;
+        else atomicAdd(dbias + n, s2);
+      }
+    }
+  }
+}
+
 // ordered reduction of the deterministic dW path: dW[n][k] += sum_s part[s][tile(n,k)][n%256][k%256] (s ascending), and
 // dbias[n] += sum over (s, tk, wk) ascending of pbias.  One thread per 4 consecutive k.
 __global__ __launch_bounds__(256) void tn256_reduce_kernel(const float* __restrict__ part, const float* __restrict__ pbias,
@@ -1752,12 +1926,12 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, true>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<0, false, true>), RING * T2_BYTES);
-  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_PLAIN, 2>), RING * T2_BYTES);
-  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_RES, 2>), RING * T2_BYTES);
-  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_GELU_PRE, 2>), RING * T2_BYTES);
-  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_ROT, 2>), RING * T2_BYTES);
-  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_EXT, 2>), RING * T2_BYTES);
-  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_GENERIC, 2>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_PLAIN>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_RES>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_GELU_PRE>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_ROT>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_EXT>), RING * T2_BYTES);
+  MEANT_RAISE_LDS((gemm_bf16_nt256p_kernel<NTE_GENERIC>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, false, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, true, false>), RING * T2_BYTES);
   MEANT_RAISE_LDS((gemm_bf16_nt256s_kernel<128, false, true>), RING * T2_BYTES);
@@ -1833,7 +2007,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
         else if (a.residual && !a.preact && !act) emode = NTE_RES;
         else if (!a.residual && a.preact && (a.epilogue & MEANT_EPI_GELU) && !(a.epilogue & MEANT_EPI_SIGMOID)) emode = NTE_GELU_PRE;
         MEANT_REQUIRE(emode >= 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: rotary epilogue with residual / activation / preact");
-#define PP_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_bf16_nt256p_kernel<MODE_, 2>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode)
+#define PP_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_bf16_nt256p_kernel<MODE_>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode)
         switch (emode) {
           case NTE_PLAIN: PP_LAUNCH(NTE_PLAIN); break;
           case NTE_RES: PP_LAUNCH(NTE_RES); break;
@@ -1926,26 +2100,39 @@ int gemm_bf16_tn_launch(const bf16* dY, int64_t lddy, const bf16* X, int64_t ldx
     int64_t splits2, rows2;
     tn256_geometry(M, N, K, splits2, rows2);
     const dim3 grid((unsigned)(ntn2 * ntk2 * splits2));
+    const bool pp = meant_opt(MEANT_OPT_TN_PP) != 0;     // ping-pong form of the 256 x 256 dW kernel
     if (det) {
       const size_t need = (size_t)(splits2 * N * K + splits2 * ntk2 * 4 * N) * sizeof(float);
       MEANT_REQUIRE(ws && ws_bytes >= need && meant_aligned16(ws), MEANT_ERR_WORKSPACE,
                     "linear_bwd_dw (deterministic): workspace of %zu bytes needed (meant_linear_bwd_dw_ws), got %zu", need, ws_bytes);
       float* part = (float*)ws;
       float* pbias = part + splits2 * N * K;
-      MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<true>, 4 * TN2_TILE);
       meant_route_hit(ROUTE_TN256_DET);
-      hipLaunchKernelGGL(gemm_bf16_tn256_kernel<true>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
-                         (int)ntk2, rows2, part, pbias);
+      if (pp) {
+        MEANT_RAISE_LDS(gemm_bf16_tn256p_kernel<true>, RING * T2_BYTES);
+        hipLaunchKernelGGL(gemm_bf16_tn256p_kernel<true>, grid, dim3(512), RING * T2_BYTES, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                           (int)ntk2, rows2, part, pbias);
+      } else {
+        MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<true>, 4 * TN2_TILE);
+        hipLaunchKernelGGL(gemm_bf16_tn256_kernel<true>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                           (int)ntk2, rows2, part, pbias);
+      }
       MEANT_LAUNCH_CHECK("gemm_bf16_tn256<det>");
       hipLaunchKernelGGL(tn256_reduce_kernel, dim3((unsigned)ceil_div(N * K / 4, 256)), dim3(256), 0, stream, part, dbias ? pbias : nullptr, dW, dbias,
                          N, K, (int)ntk2, (int)(ntn2 * ntk2), (int)splits2);
       MEANT_LAUNCH_CHECK("tn256_reduce");
       return MEANT_OK;
     }
-    MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<false>, 4 * TN2_TILE);
     meant_route_hit(ROUTE_TN256);
-    hipLaunchKernelGGL(gemm_bf16_tn256_kernel<false>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
-                       (int)ntk2, rows2, (float*)nullptr, (float*)nullptr);
+    if (pp) {
+      MEANT_RAISE_LDS(gemm_bf16_tn256p_kernel<false>, RING * T2_BYTES);
+      hipLaunchKernelGGL(gemm_bf16_tn256p_kernel<false>, grid, dim3(512), RING * T2_BYTES, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                         (int)ntk2, rows2, (float*)nullptr, (float*)nullptr);
+    } else {
+      MEANT_RAISE_LDS(gemm_bf16_tn256_kernel<false>, 4 * TN2_TILE);
+      hipLaunchKernelGGL(gemm_bf16_tn256_kernel<false>, grid, dim3(512), 4 * TN2_TILE, stream, dY, lddy, X, ldx, dW, dbias, M, N, K, (int)ntn2,
+                         (int)ntk2, rows2, (float*)nullptr, (float*)nullptr);
+    }
     MEANT_LAUNCH_CHECK("gemm_bf16_tn256");
     return MEANT_OK;
   }
