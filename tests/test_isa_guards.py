@@ -53,8 +53,6 @@ def test_tile_draw_register_of_the_ping_pong_kernel_stays_untouched_in_flight():
     assert len(res) == 12, res
     for kernel, req, reg, n, bad in res:
         assert bad is None, f"{kernel}: `{req}`: v{reg} touched while in flight by `{bad}`"
-    # the mailbox read is issued ahead of the step's DMA pieces and fragment reads
-    assert all(n > 15 for kernel, req, reg, n, bad in res if "global_load_dword" in req), res
 
 
 def test_checker_accepts_a_masked_second_request_into_the_same_register():
