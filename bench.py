@@ -18,7 +18,7 @@ gradient all-reduce overlapped with backward.  No optimizer step (the metric is 
 Weak scaling: 128 samples per GPU (global batch 1024 at 8 GPUs, BASELINE.json configs[3]).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (gemm_bf16_nt256s_kernel, MFMA-bound): algorithmic FLOPs of its launches / their
+  roofline     -- the dominant kernel (gemm_bf16_nt256p_kernel, MFMA-bound): algorithmic FLOPs of its launches / their
                   HIP-event durations.  The timed steps run the two encoder stacks on two HIP streams, where a launch
                   shares the CUs with the other stream's kernels and has no duration of its own; the events are
                   therefore taken in `roofline.timed_in` extra single-stream steps right after the timed region (the
@@ -88,8 +88,20 @@ def flops_per_sample_executed(E: int) -> float:
     return flops_per_sample(E) - saved
 
 
+def _newest_profile(pattern):
+    """newest tracked counter table under profiles/ matching the glob (names are rNN_..., so the sort order is the round order)"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return hits[-1] if hits else None
+
+
+def _dominant_kernel():
+    from meant_amd import _lib
+    return "gemm_bf16_nt256p_kernel" if _lib.get_option("nt_pp") else "gemm_bf16_nt256s_kernel"
+
+
 class GemmTimer:
-    """HIP-event timing of every launch of the dominant kernel (gemm_bf16_nt256s_kernel: the streaming bf16 NT GEMM behind
+    """HIP-event timing of every launch of the dominant kernel (gemm_bf16_nt256p_kernel: the streaming bf16 NT GEMM behind
     Linear forward, the fused q|k|v projection and every input-gradient) during the timed steps.  Events are recorded on the stream the kernel is
     launched on (torch's current stream, which the C ABI receives)."""
 
@@ -125,7 +137,7 @@ class GemmTimer:
             def __getattr__(self_, n):
                 return getattr(lib, n)
         proxy = LibProxy()
-        # the launches that gemm_bf16_nt_launch routes to gemm_bf16_nt256s_kernel: bf16, M >= 1024, M % 256 == 0, N % 256 == 0,
+        # the launches that gemm_bf16_nt_launch routes to the streaming 256 x 256 kernel (gemm_bf16_nt256p_kernel): bf16, M >= 1024, M % 256 == 0, N % 256 == 0,
         # K % 64 == 0, K >= 128, and at least half a chip of 256 x 256 tiles (fewer go to the 128 x 128 kernel)
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
 
@@ -145,7 +157,7 @@ class GemmTimer:
         es = 2.0                                                                   # bf16 activations
         # meant_linear_bwd_dw(dy, lddy, x, ldx, dw, db, M, N, K, dtype, ws, wsb, stream)
         proxy.meant_linear_bwd_dw = wrap("meant_linear_bwd_dw", lambda a: 2.0 * a[6] * a[7] * a[8] if (a[9] == 1 and a[6] >= 4096 and a[7] % 256 == 0 and a[8] % 256 == 0) else 0.0,
-                                         None, "dw_gemm (gemm_bf16_tn256_kernel)")
+                                         None, "dw_gemm (gemm_bf16_tn256p_kernel)")
         # meant_attn_fwd(qkv, o, lse, km, G, S, H, Dh, scale, causal, dtype, ws, wsb, stream)
         proxy.meant_attn_fwd = wrap("meant_attn_fwd", lambda a: 4.0 * a[4] * a[6] * a[5] * a[5] * a[7], None, "attn_fwd",
                                     lambda a: 4.0 * a[4] * a[5] * a[6] * a[7] * es)
@@ -194,10 +206,18 @@ class GemmTimer:
         """measured HBM bytes (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes: profiles/r03_c_hbm_traffic_norm_attention.json,
         produced by tools/pmc_step_kernels.py + tools/parse_pmc_kernels.py) over the algorithmic bytes that `others` prices each
         kernel at, per kind and shape.  A lookup in tracked counter files, like `traffic` -- None when they are missing."""
-        path = os.path.join(ROOT, "profiles", "r03_c_hbm_traffic_norm_attention.json")
-        if not os.path.exists(path):
+        path = _newest_profile("r*_hbm_traffic_norm_attention.json")
+        if path is None:
             return None
-        k = json.load(open(path))["kernels"]
+        doc = json.load(open(path))
+        k = doc["kernels"]
+        # the table was measured on one version of the kernels' sources: say so when a source has moved on since (ADVICE r3)
+        import hashlib
+        stale = None
+        if doc.get("source_sha16"):
+            stale = any(not os.path.exists(os.path.join(ROOT, "meant_amd", "csrc", f)) or
+                        hashlib.sha256(open(os.path.join(ROOT, "meant_amd", "csrc", f), "rb").read()).hexdigest()[:16] != h
+                        for f, h in doc["source_sha16"].items())
         def units(sub, tag, lo, hi):
             for name, v in k.items():
                 if sub in name and f"[{tag}," in name and lo <= v["in_units_of_one_token_tensor"] <= hi:
@@ -221,7 +241,8 @@ class GemmTimer:
                 ent["attn_bwd (dq + dkv, option attn_bwd1 = 0)"] = round((dq + dkv) / 9.0, 3)
                 ent["attn_bwd two-pass vs its minimum of 12"] = round((dq + dkv) / 12.0, 3)
             out[tag] = ent
-        return {"measured_over_algorithmic_hbm_bytes": out, "source": "profiles/r03_c_hbm_traffic_norm_attention.json"}
+        return {"measured_over_algorithmic_hbm_bytes": out, "source": os.path.relpath(path, ROOT),
+                "table_older_than_kernel_sources": stale}
 
     def summary(self, recs=None):
         tot_t, tot_f, n = 0.0, 0.0, 0
@@ -235,12 +256,13 @@ class GemmTimer:
 
     def traffic_per_launch(self):
         """HBM bytes per launch of the dominant kernel, averaged over the launches timed above, from the PMC table
-        in profiles/r03_nt256s_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+        in the newest profiles/rNN_nt256*_hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
         corrections applied; measured on the plain epilogue) plus the algorithmic bytes of the extra epilogue
         operands (residual read / pre-activation write).  None if a launched shape is not in the table."""
-        path = os.path.join(ROOT, "profiles", "r03_nt256s_hbm_traffic.json")
-        if not os.path.exists(path):
+        path = _newest_profile("r*_nt256*_hbm_traffic.json")
+        if path is None:
             return None
+        self.traffic_path = os.path.relpath(path, ROOT)
         doc = json.load(open(path))
         table = doc["shapes"]
         # the table was measured on one version of the kernel's source: say so when the source has moved on since
@@ -371,6 +393,8 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="run the per-GPU batch as this many micro-batches per step (gradient accumulation in the reducer's buckets, one "
                          "collective per step): --encoders 12 keeps 128 samples per GPU per step with 64 in flight and no recomputation")
+    ap.add_argument("--fp32-batch", type=int, default=0,
+                    help="also time fwd+CE+bwd of the fp32 tier (north_star's 1e-3 tolerance tier) at this batch (secondary field, never `value`)")
     ap.add_argument("--from-host", choices=["f64", "f32", "u8"], default=None,
                     help="also time the step fed by meant_amd.data.DeviceBatchLoader from host arrays of this pixel type "
                          "(PCIe-inclusive secondary figure, never `value`)")
@@ -533,6 +557,31 @@ def main():
         assert torch.isfinite(out).all().item()
         model.train(was_training)
 
+    # secondary figure: the fp32 tier (exact-f32 MFMA GEMMs, fp32 attention): fwd + CE + bwd at a small batch
+    fp32_ms = None
+    if args.fp32_batch > 0:
+        Bf = min(args.fp32_batch, B)
+        model.compute_dtype = torch.float32
+        f_in, f_tgt = tuple(t[:Bf] for t in inputs), target[:Bf]
+
+        def fstep():
+            reducer.prepare()
+            l_ = cross_entropy_on_probs(model(*f_in), f_tgt)
+            l_.backward()
+            reducer.wait()
+            return l_
+        for _ in range(2):
+            fstep()
+        barrier()
+        t1 = time.perf_counter()
+        nf = max(2, min(args.steps, 5))
+        for _ in range(nf):
+            l_ = fstep()
+        barrier()
+        fp32_ms = (time.perf_counter() - t1) / nf * 1e3
+        assert torch.isfinite(l_).item()
+        model.compute_dtype = torch.bfloat16
+
     # secondary figure: the same step fed from HOST arrays in the data set's storage type through the double-buffered
     # loader (gather into pinned memory, H2D on its own stream, conversion + normalisation + patchify on the device)
     host_ms = None
@@ -580,10 +629,10 @@ def main():
         n, gf, gt = timer.summary()
         achieved = gf / gt / 1e12 if gt > 0 else 0.0
         traffic = timer.traffic_per_launch() if (B == 128 and MODEL == "meant") else None   # the PMC table holds the headline's shapes
-        roofline = {"kernel": "gemm_bf16_nt256s_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+        roofline = {"kernel": _dominant_kernel(), "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic),
-                    "traffic_source": "profiles/r03_nt256s_hbm_traffic.json (rocprofv3 PMC passes; lookup by launched shape)",
+                    "traffic_source": f"{getattr(timer, 'traffic_path', None)} (rocprofv3 PMC passes; lookup by launched shape)",
                     "traffic_table_older_than_kernel_source": getattr(timer, "traffic_stale", None),
                     "launches_timed": n, "avg_launch_ms": round(gt / max(n, 1) * 1e3, 4),
                     "avg_launch_gflop": round(gf / max(n, 1) / 1e9, 2),
@@ -623,6 +672,13 @@ def main():
         if opt_ms is not None:
             res["with_optimizer"] = {"ms_per_step": round(opt_ms, 3), "samples_per_s": round(world * B / opt_ms * 1e3, 2),
                                      "what": "fwd+CE+bwd + global-norm clip(1.0) + fused AdamW on the flat fp32 buckets"}
+        if fp32_ms is not None:
+            Bf = min(args.fp32_batch, B)
+            sps32 = world * Bf / fp32_ms * 1e3
+            res["fp32_tier"] = {"batch_per_gpu": Bf, "ms_per_step": round(fp32_ms, 3), "samples_per_s": round(sps32, 2),
+                                "whole_step_f32_matrix_frac": round(sps32 / world * flops_per_sample_executed(E) / 157.3e12, 4),
+                                "what": "same model and step with compute_dtype float32: every product on v_mfma_f32_32x32x2_f32 (exact f32, "
+                                        "157.3 TFLOP/s peak), fp32 attention; the tier north_star's 1e-3 tolerance is stated for"}
         if host_ms is not None:
             bytes_per_sample = L * C * IMG * IMG * {"f64": 8, "f32": 4, "u8": 1}[args.from_host] + L * S * 12 + 8
             res["from_host"] = {"pixels": args.from_host, "ms_per_step": round(host_ms, 3),

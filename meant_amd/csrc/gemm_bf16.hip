@@ -916,26 +916,29 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
     tabA = (sec ? a.rot_ka : a.rot_qa) + c;
     tabB = (sec ? a.rot_kb : a.rot_qb) + c;
   }
-  f32x4 ta[2][2], tb[2][2];                        // [h][half]
-  bf16x8 xres[2] = {}, xsub[2] = {};
+  // Operand registers of a round.  In the rotary and residual modes there are TWO sets and a round's operands are requested two
+  // rounds ahead (a round is ~500 cycles, an L2 hit under this kernel's own load more): set i & 1 serves round i and is refilled
+  // for round i + 2 as soon as round i has consumed it.  The extended mode has no registers to spare (253) and keeps one set, one
+  // round ahead.  Either way a round's requests go out BEFORE its stores -- loads never queue behind stores (vmcnt retires in order).
+  constexpr int NS = (MODE == NTE_ROT || MODE == NTE_RES) ? 2 : 1;
+  f32x4 ta[NS][2][2], tb[NS][2][2];                // [set][h][half]
+  bf16x8 xres[NS][2] = {}, xsub[2] = {};
   float xrs[2] = {1.f, 1.f}, xkc[2] = {0.f, 0.f};
   f32x4 xbr[2][2] = {};
-  // one register set: a round's operands are consumed (both rows finished), THEN the next round's are requested into the same
-  // registers, THEN the round's stores go out -- loads never queue behind stores
-  auto load_ops = [&](int i) {
+  auto load_ops = [&](int i, int st) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int64_t m = mrow + i * 16 + 8 * h;
       if (ROT) {
         if (rot_on) {
           const int64_t o = (int64_t)(m % a.rot_S) * a.rot_R;
-          ta[h][0] = *gp(reinterpret_cast<const f32x4*>(tabA + o));
-          ta[h][1] = *gp(reinterpret_cast<const f32x4*>(tabA + o + 4));
-          tb[h][0] = *gp(reinterpret_cast<const f32x4*>(tabB + o));
-          tb[h][1] = *gp(reinterpret_cast<const f32x4*>(tabB + o + 4));
+          ta[st][h][0] = *gp(reinterpret_cast<const f32x4*>(tabA + o));
+          ta[st][h][1] = *gp(reinterpret_cast<const f32x4*>(tabA + o + 4));
+          tb[st][h][0] = *gp(reinterpret_cast<const f32x4*>(tabB + o));
+          tb[st][h][1] = *gp(reinterpret_cast<const f32x4*>(tabB + o + 4));
         }
       } else {
-        if (f_res) xres[h] = __builtin_nontemporal_load(gp(reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n)));
+        if (f_res) xres[st][h] = __builtin_nontemporal_load(gp(reinterpret_cast<const bf16x8*>(a.residual + m * a.ldr + n)));
         if (EXT) {
           if (a.row_scale) xrs[h] = *gp(a.row_scale + m);
           if (a.sub) {
@@ -951,17 +954,22 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
       }
     }
   };
-  load_ops(0);
+  load_ops(0, 0);
+  if (NS == 2) load_ops(1, 1);
 #ifdef PP_LAB_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PPSTAMP(3)
 #endif
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int u = i & 1;                           // alternate between the two patches
+  auto patch_write = [&](int i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      asm volatile("ds_write_b128 %0, %1" ::"v"(pw[u] + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
+      asm volatile("ds_write_b128 %0, %1" ::"v"(pw[i & 1] + (((j * 4 + fkg) ^ frow) << 4)), "v"(acc[i][j]) : "memory");
+  };
+  patch_write(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int u = i & 1;                           // the two patches alternate
+    const int st = NS == 2 ? u : 0;
     // both rows of the round come back in ONE asm statement that also waits for them: hipcc does not know an asm ds_read is
     // asynchronous and may copy its destination before a wait that sits in a later statement (tools/isa_inflight_check.py)
     f32x4 lo[2], hi[2];
@@ -974,6 +982,8 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
                      "v"(b1 + (((2 * oc + 1) ^ r1) << 4))
                    : "memory");
     }
+    // the NEXT round's accumulators go into the other patch now: their LDS round trip runs under this round's arithmetic
+    if (i + 1 < 8) patch_write(i + 1);
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 outv[2], prev[2];
 #pragma unroll
@@ -985,7 +995,7 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
 #pragma unroll
         for (int e = 0; e < 8; ++e) prev[h][e] = (bf16)v[e];
       }
-      if (ROT && rot_on) rot_apply8(v, ta[h][0], ta[h][1], tb[h][0], tb[h][1]);
+      if (ROT && rot_on) rot_apply8(v, ta[st][h][0], ta[st][h][1], tb[st][h][0], tb[st][h][1]);
       if (f_gelu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
@@ -996,7 +1006,7 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
       }
       if (f_res) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)xres[h][e];
+        for (int e = 0; e < 8; ++e) v[e] += (float)xres[st][h][e];
       }
       if (EXT) {
         if (a.sub) {
@@ -1012,7 +1022,7 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
       for (int e = 0; e < 8; ++e) outv[h][e] = (bf16)v[e];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < 8) load_ops(i + 1);
+    if (i + NS < 8) load_ops(i + NS, st);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {

@@ -64,8 +64,12 @@ class FusedAdamW:
     """torch.optim.AdamW + torch.nn.utils.clip_grad_norm_ semantics on the reducer's flat buckets.
 
         red = GradReducer(model.parameters()); opt = FusedAdamW(red, lr=5e-5, max_grad_norm=1.0)
-        red.prepare(); loss.backward(); red.wait(); opt.step()
-    """
+        red.prepare(); loss = f(model(x)); loss.backward(); red.wait(); opt.step()
+
+    (`prepare()` comes BEFORE the forward pass: it also clears the per-step gradient-sink claims the forward's ops make.)
+    `state_dict()` / `load_state_dict()` carry the step count, the learning rate and both moment buffers: a fresh optimizer over a
+    model with the same parameter registration order continues exactly (checkpoint_train.py:217-219,333-336 of the reference
+    saves and restores `optimizer.state_dict()` the same way)."""
 
     def __init__(self, reducer: GradReducer, lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, max_grad_norm: Optional[float] = None):
@@ -129,6 +133,13 @@ class CosineWarmRestarts:
 
     def step(self):
         self.epoch += 1
+        self.opt.lr = self.lr_at(self.epoch)
+
+    def state_dict(self):
+        return {"epoch": self.epoch, "base_lr": self.base_lr, "T_0": self.T_0, "eta_min": self.eta_min}
+
+    def load_state_dict(self, sd):
+        self.epoch, self.base_lr, self.T_0, self.eta_min = sd["epoch"], sd["base_lr"], sd["T_0"], sd["eta_min"]
         self.opt.lr = self.lr_at(self.epoch)
 
 

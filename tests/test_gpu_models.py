@@ -58,11 +58,34 @@ def test_meant_tiny_golden(golden, dev, dtype):
     _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), dtype, dev)
 
 
+@pytest.mark.parametrize("fold", [False, True], ids=["separate_norms", "norm_folded"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-def test_meant_tiny_two_layers_golden(golden, dev, dtype):
+def test_meant_tiny_two_layers_golden(golden, dev, dtype, fold, monkeypatch):
+    """fold: the RMSNorm-into-Linear fold (ops.FUSE_NORM_LINEAR) is what `--encoders 12` runs at 128 samples per GPU; the
+    reference-generated fixture pins it as well as the separate kernels (the fp32 tier has no folded path: same run twice)"""
+    from meant_amd import ops
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", fold)
     g = golden("meant_tiny_e2")
     _, hip = _mk("meant", (128, 192, 4, 32, 48, 16, 2, 3), dict(num_heads=2, num_encoders=2, channels=4), (50, 128), dev)
+    before = list(ops.fold_calls)
     _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), dtype, dev)
+    if dtype == torch.bfloat16:
+        assert (ops.fold_calls[1] > before[1]) == fold       # the folded kernels really ran (or really did not)
+
+
+@pytest.mark.parametrize("det", [0, 1], ids=["atomics", "deterministic"])
+def test_meant_tiny_golden_deterministic_option(golden, dev, det):
+    """MEANT_DETERMINISTIC=1 (ordered dW / dbias / embedding / gain reductions) against the same reference-generated fixture"""
+    from meant_amd import _lib
+    old = _lib.get_option("deterministic")
+    _lib.set_option("deterministic", det)
+    try:
+        g = golden("meant_tiny")
+        for dtype in DTYPES:
+            _, hip = _mk("meant", (128, 128, 4, 32, 32, 16, 3, 2), dict(num_heads=2, num_encoders=1, channels=4), (100, 128), dev)
+            _run_golden(g, hip, (t(g["in_tweets"]), t(g["in_images"]), t(g["in_mask"])), dtype, dev)
+    finally:
+        _lib.set_option("deterministic", old)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
@@ -96,9 +119,15 @@ def test_meant_vision_c2_golden(golden, dev, dtype):
     _run_golden(g, hip, (img,), dtype, dev)
 
 
+@pytest.mark.parametrize("fold", [False, True], ids=["separate_norms", "norm_folded"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-def test_meant_full_c3_golden(golden, dev, dtype):
-    """BASELINE config 3 at full dims: lag 12, d 768, 12 heads, S 512, 224x224 (B=2, V=2000)."""
+def test_meant_full_c3_golden(golden, dev, dtype, fold, monkeypatch):
+    """BASELINE config 3 at full dims: lag 12, d 768, 12 heads, S 512, 224x224 (B=2, V=2000); with the RMSNorm-into-Linear fold
+    off and on (bf16 tier; the fp32 tier has no folded path and is run once)."""
+    from meant_amd import ops
+    if fold and dtype != torch.bfloat16:
+        pytest.skip("the fold exists in the bf16 tier only")
+    monkeypatch.setattr(ops, "FUSE_NORM_LINEAR", fold)
     g = golden("meant_full_c3")
     r = np.random.RandomState(99)
     ids = t(r.randint(0, 2000, (2, 12, 512)).astype("int64"))

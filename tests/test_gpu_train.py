@@ -42,6 +42,58 @@ def test_ce_on_probs_out_of_range_target_is_flagged(dev):
         assert torch.isnan(probs.grad[2]).all() and torch.isfinite(probs.grad[[0, 1, 3, 4, 5]]).all()
 
 
+def test_optimizer_and_scheduler_resume_continue_identically(dev):
+    """checkpoint_train.py:217-219,333-336 / in_loop_train.py:547-567 of the reference save and restore `model.state_dict()`,
+    `optimizer.state_dict()` and the scheduler: a FRESH model + TrainStep + CosineWarmRestarts loaded from the three state dicts
+    after step 3 (epoch 8, i.e. one epoch past the warm restart at 7) must take the next steps exactly as the original run does.
+    Train mode (the dropout masks are drawn from the torch seed set before every step), deterministic reductions, so "exactly" is
+    bit for bit."""
+    import meant_amd
+    from meant_amd import _lib
+    from meant_amd.train import TrainStep, CosineWarmRestarts
+    old = _lib.get_option("deterministic")
+    _lib.set_option("deterministic", 1)
+    try:
+        def make():
+            torch.manual_seed(0)
+            m = meant_amd.meant(128, 128, 4, 32, 32, 16, 3, 2, torch.nn.Embedding(100, 128), num_heads=2, num_encoders=2).to(dev).train()
+            m.compute_dtype = torch.bfloat16
+            ts = TrainStep(m, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+            return m, ts, CosineWarmRestarts(ts.opt, T_0=7, eta_min=1e-5)
+        g = torch.Generator().manual_seed(5)
+        ids = torch.randint(0, 100, (8, 3, 16), generator=g).to(dev)
+        img = torch.randn(8, 3, 4, 32, 32, generator=g).to(dev)
+        mask = torch.ones(8, 3, 16, device=dev)
+        tgt = torch.tensor([0, 1, 0, 1, 1, 0, 1, 0], device=dev)
+
+        def steps(ts, sched, first, n):
+            for i in range(first, first + n):
+                torch.manual_seed(100 + i)
+                ts(ids, img, mask, target=tgt)
+                sched.step()
+        m, ts, sched = make()
+        for _ in range(5):                                   # epochs 1..5 without training: the restart at 7 is then inside the test
+            sched.step()
+        steps(ts, sched, 0, 3)                               # epochs 6, 7 (lr back at its base value), 8
+        assert sched.epoch == 8 and abs(sched.lr_at(7) - 1e-3) < 1e-12
+        saved = {"model": {k: v.clone() for k, v in m.state_dict().items()}, "opt": ts.opt.state_dict(), "sched": sched.state_dict()}
+        steps(ts, sched, 3, 2)
+        want = {k: v.clone() for k, v in m.state_dict().items()}
+        m2, ts2, sched2 = make()
+        with torch.no_grad():
+            for p in m2.parameters():                        # a different starting point: everything must come from the state dicts
+                p.add_(0.123)
+        m2.load_state_dict(saved["model"])
+        ts2.opt.load_state_dict(saved["opt"])
+        sched2.load_state_dict(saved["sched"])
+        assert ts2.opt.step_count == 3 and ts2.opt.lr == sched2.lr_at(8)
+        steps(ts2, sched2, 3, 2)
+        for k, v in m2.state_dict().items():
+            assert torch.equal(v, want[k]), k
+    finally:
+        _lib.set_option("deterministic", old)
+
+
 @pytest.mark.parametrize("max_norm", [None, 1.0, 1e-3])
 def test_fused_adamw_matches_torch(dev, max_norm):
     """3 steps of clip_grad_norm_ + torch.optim.AdamW on the CPU vs the fused flat-bucket kernels"""

@@ -161,3 +161,26 @@ def test_rotary_tables_match_golden(golden):
         k = torch.from_numpy(g[f"k{S}"])[..., :48]
         sw = torch.stack((-k[..., 1::2], k[..., 0::2]), -1).reshape(k.shape)
         np.testing.assert_allclose((k * ka + sw * kb).numpy(), g[f"rk{S}"][..., :48], atol=2e-5)
+
+
+def test_cosine_warm_restarts_matches_torch_over_two_periods():
+    """meant_amd.train.CosineWarmRestarts against torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(T_0 = 7, eta_min) stepped
+    once per epoch (in_loop_train.py:547-567): same learning rate at every epoch through two restarts, and after a
+    state_dict() -> load_state_dict() into a fresh scheduler"""
+    from meant_amd.train import CosineWarmRestarts
+
+    class Opt:
+        lr = 5e-5
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.SGD([p], lr=5e-5)
+    ref = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(ref_opt, T_0=7, T_mult=1, eta_min=1e-6)
+    mine = CosineWarmRestarts(Opt(), T_0=7, eta_min=1e-6)
+    for epoch in range(1, 16):
+        ref_opt.step(); ref.step(); mine.step()
+        assert abs(mine.opt.lr - ref_opt.param_groups[0]["lr"]) < 1e-12, epoch
+        if epoch in (7, 14):
+            assert abs(mine.opt.lr - 5e-5) < 1e-15          # the warm restart
+        if epoch == 9:
+            again = CosineWarmRestarts(Opt(), T_0=3, eta_min=0.0)
+            again.load_state_dict(mine.state_dict())
+            assert again.epoch == 9 and again.opt.lr == mine.opt.lr and again.lr_at(12) == mine.lr_at(12)
