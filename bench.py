@@ -393,6 +393,8 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="run the per-GPU batch as this many micro-batches per step (gradient accumulation in the reducer's buckets, one "
                          "collective per step): --encoders 12 keeps 128 samples per GPU per step with 64 in flight and no recomputation")
+    ap.add_argument("--extra-streams", type=int, default=0,
+                    help="lab: create (and touch once) this many more HIP streams before the model runs -- DESIGN.md section 7, the stream-count cliff")
     ap.add_argument("--fp32-batch", type=int, default=0,
                     help="also time fwd+CE+bwd of the fp32 tier (north_star's 1e-3 tolerance tier) at this batch (secondary field, never `value`)")
     ap.add_argument("--from-host", choices=["f64", "f32", "u8"], default=None,
@@ -434,6 +436,11 @@ def main():
     if args.two_streams >= 0:
         import meant_amd.modules as _mm
         _mm.TWO_STREAMS = bool(args.two_streams)
+    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(args.extra_streams)]
+    for es in extra_streams:                        # a stream gets its hardware queue at first use
+        with torch.cuda.stream(es):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
     timer = GemmTimer()
     timer.install()
     E, B = args.encoders, args.batch_per_gpu
