@@ -58,10 +58,16 @@ def _side_stream(device):
 # With TWO_STREAMS the LANGUAGE stack -- the longer of the two, i.e. the step's critical path -- runs on a high-priority stream of its
 # own, so that its kernels are placed ahead of the vision stack's when both are waiting for CUs: 43.00 -> 42.90 ms median over three
 # alternating pairs of 30-step runs on one box (+0.2 %; MEANT_LANG_PRIORITY=0 runs it on the caller's stream as before)
-# Default: on for a single-process run, OFF under a multi-process launch (WORLD_SIZE > 1): there the gradient reducer's launch stream
-# and RCCL's own stream come on top of main + vision, and a fifth stream in the process cost this step 11 % where it was measured
-# (one GPU).  +0.2 % is not worth that risk unmeasured; MEANT_LANG_PRIORITY=1 forces it on.
-_multi = int(_os.environ.get("WORLD_SIZE", "1") or "1") > 1
+# Default: on for a single-process run, OFF wherever a gradient collective runs beside the backward pass (a multi-process launch,
+# WORLD_SIZE > 1, or its one-GPU rehearsal MEANT_REDUCE_ALWAYS=1).  Measured in round 4 (profiles/r04_stream_queues.txt,
+# tools/lab/stream_cliff*.sh: one-rank RCCL group on one MI355X, three alternating runs each, stream -> hardware-queue map from
+# rocprofv3 --kernel-trace): plain step 37.7 ms; with the reducer's collectives and the priority stream 39.0 ms on the runtime's
+# default four hardware queues (main and the language stream end up sharing one) and 42.4 ms -- the "fifth-stream cliff" of round 3 --
+# once every stream has a queue of its own (GPU_MAX_HW_QUEUES=8): three compute queues, one of them high priority, plus the
+# collective's.  Without the priority stream (language stack on the caller's stream, two compute queues + the collective's):
+# 39.5 ms on four queues, 38.3 ms on eight, the best of all: bench.py exports GPU_MAX_HW_QUEUES=8 for such launches.
+# MEANT_LANG_PRIORITY=1 forces the priority stream on.
+_multi = int(_os.environ.get("WORLD_SIZE", "1") or "1") > 1 or _os.environ.get("MEANT_REDUCE_ALWAYS") == "1"
 LANG_PRIORITY = _os.environ.get("MEANT_LANG_PRIORITY", "0" if _multi else "1") != "0"
 _HI = {}
 

@@ -51,7 +51,11 @@ for (key, tag), ls in agg.items():
             "launches": c["n"], "fetch_bytes_corrected": round(f), "write_bytes": round(w), "hbm_bytes": round(f + w),
             "in_units_of_one_token_tensor": round((f + w) / (T[tag] * D * e), 3),
             "read_tensors": round(f / (T[tag] * D * e), 3), "written_tensors": round(w / (T[tag] * D * e), 3)}
-json.dump({"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_step_kernels.py; bytes = 2 * FETCH_SIZE "
+import hashlib, os
+_csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "meant_amd", "csrc")
+_sha = {f: hashlib.sha256(open(os.path.join(_csrc, f), "rb").read()).hexdigest()[:16] for f in ("norm.hip", "attn_bf16.hip", "attn_bwd1.hip")}
+json.dump({"source_sha16": _sha,      # bench.py flags the table as older than the kernels when a source has moved on since
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_step_kernels.py; bytes = 2 * FETCH_SIZE "
                      "* 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads); one token tensor = T x 768 bf16 "
                      "(text T = 786432: 1.208 GB; vision T = 301056: 0.462 GB)", "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

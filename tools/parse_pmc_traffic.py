@@ -13,7 +13,7 @@ def per_dispatch(d, counter):
     f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     vals = []
     for r in csv.DictReader(open(f)):
-        if "gemm_bf16_nt256s_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if ("gemm_bf16_nt256p_kernel" in r["Kernel_Name"] or "gemm_bf16_nt256s_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     vals.sort()
     return [v for _, v in vals]
@@ -36,7 +36,7 @@ for i, (M, N, K) in enumerate(SHAPES):
         res[f"{M},{N},{K}"]["read_requests_to_dram_share"] = round(dd / q, 3) if q else None
 import hashlib, os
 _src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "meant_amd", "csrc", "gemm_bf16.hip")
-json.dump({"kernel": "gemm_bf16_nt256s_kernel", "kernel_source": "meant_amd/csrc/gemm_bf16.hip",
+json.dump({"kernel": "gemm_bf16_nt256p_kernel (ping-pong streaming NT GEMM; nt_pp = 0 launches gemm_bf16_nt256s_kernel)", "kernel_source": "meant_amd/csrc/gemm_bf16.hip",
            "kernel_source_sha16": hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16],   # bench.py flags the table as stale when the source moves on
             "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
            "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)", "shapes": res},

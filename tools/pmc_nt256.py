@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch gemm_bf16_nt256s_kernel once per shape the bench step uses (plain epilogue), 3 times each, so that
+"""Launch the streaming NT GEMM (gemm_bf16_nt256p_kernel) once per shape the bench step uses (plain epilogue), 3 times each, so that
 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) can attribute HBM traffic per shape.
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python tools/pmc_nt256.py"""
 import math, os, sys
