@@ -876,6 +876,13 @@ __device__ __forceinline__ unsigned long long pp_now() {
 // (2.5 k cycles per round, 20 k of a 64 k-cycle tile at K = 768: round 4, tools/lab/stamp_pp.py) -- a store is fire-and-forget
 // only while nothing behind it asks for the counter.
 enum { NTE_PLAIN = 0, NTE_RES, NTE_GELU_PRE, NTE_ROT, NTE_EXT, NTE_GENERIC };
+// Output stores as write-through (sc1) stores: a plain store leaves its line in the XCD's 4 MiB L2 (MI355X_MICROARCH.md, "stores of
+// each flavour"), and a tile's 128 KiB of output per CU push the A panels the neighbouring CUs are about to re-read out of it.
+// Measured (profiles/r04_nt256p_hbm_traffic*.json): HBM traffic 1.175x -> 1.08x of the algorithmic bytes at N = K = 768, 1.72x ->
+// 1.65x at N = 2304; +1-2 % throughput.  PP_STORE_SC1=0 builds the plain stores.
+#ifndef PP_STORE_SC1
+#define PP_STORE_SC1 1
+#endif
 #define GAS __attribute__((address_space(1)))
 template <typename T> __device__ __forceinline__ const GAS T* gp(const T* p) { return (const GAS T*)p; }
 template <typename T> __device__ __forceinline__ GAS T* gpw(T* p) { return (GAS T*)p; }
@@ -907,20 +914,39 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
   // rotary epilogue (fused q|k|v projection): the lane's 8 columns sit at a fixed place c of a q or k head for the whole tile,
   // only the position m mod S changes.  vmcnt retires in order, so a table load issued after a round's output stores would wait
   // for those stores to be acknowledged: the operands of round r+1 are requested BEFORE the stores of round r go out.
-  bool rot_on = false;
+  // The tile lies inside ONE of the q | k | v sections (256 divides H * Dh = 768; the launcher checks it), so "does this tile rotate
+  // at all" is wave-uniform; inside a rotating tile every lane requests table rows (a lane whose 8 columns lie beyond the rotary
+  // dimension reads the row's first columns and drops them): no divergent branch around the requests.  The position m mod S of a
+  // lane's rows is formed ONCE per tile and stepped: a 64-bit modulo per row was ~60 of a round's 440 instructions.
+  bool tile_rot = false, rot_on = false;
   const float *tabA = nullptr, *tabB = nullptr;
+  unsigned posb = 0;
+  const unsigned rS = ROT ? (unsigned)a.rot_S : 1u;
+  const bool bigS = rS >= 256u;                        // then a lane's 16 rows of a tile wrap around S at most once
   if (ROT) {
-    const int sec = (int)(n / a.rot_D);
+    const int sec = __builtin_amdgcn_readfirstlane((int)((n0 + wn * 64) / a.rot_D));
     const int c = (int)((n - (int64_t)sec * a.rot_D) % a.rot_Dh);
-    rot_on = sec < 2 && c < a.rot_R;
-    tabA = (sec ? a.rot_ka : a.rot_qa) + c;
-    tabB = (sec ? a.rot_kb : a.rot_qb) + c;
+    tile_rot = sec < 2;
+    rot_on = tile_rot && c < a.rot_R;
+#ifdef PP_LAB_ROT_BCAST
+    tabA = (sec ? a.rot_ka : a.rot_qa);
+    tabB = (sec ? a.rot_kb : a.rot_qb);
+#else
+    tabA = (sec ? a.rot_ka : a.rot_qa) + (rot_on ? c : 0);
+    tabB = (sec ? a.rot_kb : a.rot_qb) + (rot_on ? c : 0);
+#endif
+    posb = (unsigned)(mrow % (int64_t)rS);
   }
-  // Operand registers of a round.  In the rotary and residual modes there are TWO sets and a round's operands are requested two
-  // rounds ahead (a round is ~500 cycles, an L2 hit under this kernel's own load more): set i & 1 serves round i and is refilled
-  // for round i + 2 as soon as round i has consumed it.  The extended mode has no registers to spare (253) and keeps one set, one
+  auto pos_of = [&](int i, int h) {
+    const unsigned p = posb + (unsigned)(i * 16 + 8 * h);
+    return bigS ? (p >= rS ? p - rS : p) : p % rS;
+  };
+  // Operand registers of a round.  In the rotary mode there are TWO sets and a round's operands are requested two rounds ahead
+  // (a round is ~500 cycles, an L2 hit under this kernel's own load more): set i & 1 serves round i and is refilled for round
+  // i + 2 as soon as round i has consumed it.  The residual mode requests all eight rounds' rows (64 registers) before the first
+  // round: nothing is ever requested behind a store (see DEFER).  The extended mode has no registers to spare (253) and keeps one set, one
   // round ahead.  Either way a round's requests go out BEFORE its stores -- loads never queue behind stores (vmcnt retires in order).
-  constexpr int NS = (MODE == NTE_ROT || MODE == NTE_RES) ? 2 : 1;
+  constexpr int NS = MODE == NTE_ROT ? 2 : MODE == NTE_RES ? 8 : 1;   // residual mode: all eight rounds' rows requested up front
   f32x4 ta[NS][2][2], tb[NS][2][2];                // [set][h][half]
   bf16x8 xres[NS][2] = {}, xsub[2] = {};
   float xrs[2] = {1.f, 1.f}, xkc[2] = {0.f, 0.f};
@@ -930,8 +956,12 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
     for (int h = 0; h < 2; ++h) {
       const int64_t m = mrow + i * 16 + 8 * h;
       if (ROT) {
-        if (rot_on) {
-          const int64_t o = (int64_t)(m % a.rot_S) * a.rot_R;
+        if (tile_rot) {
+#ifdef PP_LAB_ROT_BCAST
+          const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane((int)(pos_of(i, h) * (unsigned)a.rot_R));   // lab: one address per wave (wrong values)
+#else
+          const unsigned o = pos_of(i, h) * (unsigned)a.rot_R;
+#endif
           ta[st][h][0] = *gp(reinterpret_cast<const f32x4*>(tabA + o));
           ta[st][h][1] = *gp(reinterpret_cast<const f32x4*>(tabA + o + 4));
           tb[st][h][0] = *gp(reinterpret_cast<const f32x4*>(tabB + o));
@@ -954,12 +984,23 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
       }
     }
   };
-  load_ops(0, 0);
-  if (NS == 2) load_ops(1, 1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) load_ops(i, i);
 #ifdef PP_LAB_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PPSTAMP(3)
 #endif
+  // output rows by running pointers (rows 8 apart: cstep8 elements): no 64-bit multiply per row
+  const int64_t cstep8 = 8 * a.ldc;
+  bf16* cp = a.C + mrow * a.ldc + n;
+  bf16* pp = f_pre ? a.preact + mrow * a.ldc + n : nullptr;
+  // vmcnt retires in order: a round's operand request issued behind an earlier round's output stores completes only when those
+  // stores have been ACKNOWLEDGED by memory (microseconds under this kernel's own load) -- the rotary projection ran at 0.90 PFLOP/s
+  // beside 1.14 for the plain epilogue, and neither fewer instructions per round (440 -> 200) nor one table address per wave
+  // changed that.  In the rotary mode the finished rows are therefore HELD in registers (the accumulators drain twice as fast as
+  // they fill: 16 registers freed, 8 taken per round) and stored after the last round's requests are out: 0.95-0.99 PFLOP/s.
+  constexpr bool DEFER = MODE == NTE_ROT;
+  bf16x8 held[DEFER ? 8 : 1][2];
   auto patch_write = [&](int i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -969,7 +1010,7 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int u = i & 1;                           // the two patches alternate
-    const int st = NS == 2 ? u : 0;
+    const int st = NS == 2 ? u : NS == 8 ? i : 0;
     // both rows of the round come back in ONE asm statement that also waits for them: hipcc does not know an asm ds_read is
     // asynchronous and may copy its destination before a wait that sits in a later statement (tools/isa_inflight_check.py)
     f32x4 lo[2], hi[2];
@@ -995,7 +1036,14 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
 #pragma unroll
         for (int e = 0; e < 8; ++e) prev[h][e] = (bf16)v[e];
       }
-      if (ROT && rot_on) rot_apply8(v, ta[st][h][0], ta[st][h][1], tb[st][h][0], tb[st][h][1]);
+      if (ROT && tile_rot) {
+        float w8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w8[e] = v[e];
+        rot_apply8(w8, ta[st][h][0], ta[st][h][1], tb[st][h][0], tb[st][h][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rot_on ? w8[e] : v[e];
+      }
       if (f_gelu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
@@ -1024,15 +1072,45 @@ __device__ __forceinline__ void nt256_wave_epilogue(const GemmBf16Args& a, f32x4
     __builtin_amdgcn_sched_barrier(0);
     if (i + NS < 8) load_ops(i + NS, st);
     __builtin_amdgcn_sched_barrier(0);
+    if (DEFER) {                                   // rotary / residual modes: see `held`
+      held[i][0] = outv[0];
+      held[i][1] = outv[1];
+      continue;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int64_t m = mrow + i * 16 + 8 * h;
+      bf16* const cq = cp + (h ? cstep8 : 0);
+      bf16* const pq = f_pre ? pp + (h ? cstep8 : 0) : nullptr;
 #ifndef PP_LAB_NOSTORE
-      if (f_pre) *gpw(reinterpret_cast<bf16x8*>(a.preact + m * a.ldc + n)) = prev[h];
-      *gpw(reinterpret_cast<bf16x8*>(a.C + m * a.ldc + n)) = outv[h];
+#if PP_STORE_SC1
+      // write-through stores (see PP_STORE_SC1).  The s_nop: the data registers of a 16-byte store may be rewritten right behind it
+      // only after a wait state, which hipcc inserts for its own stores and cannot know about here
+      if (f_pre) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(pq), "v"(prev[h]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(cq), "v"(outv[h]) : "memory");
 #else
-      asm volatile("" ::"v"(outv[h]), "v"(prev[h]));
+      if (f_pre) *gpw(reinterpret_cast<bf16x8*>(pq)) = prev[h];
+      *gpw(reinterpret_cast<bf16x8*>(cq)) = outv[h];
 #endif
+#else
+      asm volatile("" ::"v"(outv[h]), "v"(prev[h]), "v"(cq), "v"(pq));
+#endif
+    }
+    cp += 2 * cstep8;
+    if (f_pre) pp += 2 * cstep8;
+  }
+  if (DEFER) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16* const cq = cp + (h ? cstep8 : 0);
+#if PP_STORE_SC1
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(cq), "v"(held[i][h]) : "memory");
+#else
+        *gpw(reinterpret_cast<bf16x8*>(cq)) = held[i][h];
+#endif
+      }
+      cp += 2 * cstep8;
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the wave is out of its patches
