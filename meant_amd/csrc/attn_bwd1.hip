@@ -704,19 +704,29 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(Bwd1Args args) {
       __builtin_amdgcn_wave_barrier();
       store_transposed(dkacc, a.scale, myreg, dqkv + D, ld, key0, S, ln, 2);
     } else if (key0 < S) {                                   // dead padding: exact zeros
-      const u32x4 z = {0u, 0u, 0u, 0u};
+      // (the lane index through an empty asm: otherwise hipcc forms the eight per-lane row offsets of these stores once at kernel
+      // entry, spills them (the kernel sits at 256 registers) and reloads each one from scratch in front of its store -- a
+      // scratch reload is a vector-memory load, and the vmcnt(0) behind it also waits for the PREVIOUS store's acknowledgement:
+      // the zero rows of a dead key half went out one store round trip at a time.  Round 4, found in the ISA)
+      int ln = lane;
+      unsigned zz = 0;                                       // (likewise the zeros: as a constant they are parked in scratch too)
+      asm volatile("" : "+v"(ln), "+v"(zz));
+      const u32x4 z = {zz, zz, zz, zz};
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int idx = it * 64 + lane;
+        const int idx = it * 64 + ln;
         const int row = idx >> 4, cc = idx & 15;
         if (key0 + row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)(key0 + row) * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
       }
     }
     if (hk == 0 && upper_dead(sk)) {                         // the upper key half of this item was dead padding: exact zeros
-      const u32x4 z = {0u, 0u, 0u, 0u};
+      int ln = lane;
+      unsigned zz = 0;
+      asm volatile("" : "+v"(ln), "+v"(zz));
+      const u32x4 z = {zz, zz, zz, zz};
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int idx = it * 64 + lane;
+        const int idx = it * 64 + ln;
         const int row = 256 + wave * 32 + (idx >> 4), cc = idx & 15;
         if (row < S) *reinterpret_cast<u32x4*>(dqkv + (int64_t)row * ld + (1 + (cc >> 3)) * D + (cc & 7) * 8) = z;
       }

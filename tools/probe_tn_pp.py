@@ -22,13 +22,14 @@ for (M, N, K) in shapes:
         for _ in range(n): run()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
-    res = {0: [], 1: []}
+    PPS = [int(v) for v in os.environ.get("PROBE_TN", "0,1").split(",")]
+    res = {v: [] for v in PPS}
     for r in range(rounds):
-        for pp in (0, 1):
+        for pp in PPS:
             check(lib.meant_set_option(b"tn_pp", pp), "opt")
             res[pp].append(timed())
     outs = {}
-    for pp in (0, 1):
+    for pp in PPS:
         check(lib.meant_set_option(b"tn_pp", pp), "opt")
         dw.zero_(); db.zero_()
         run(); torch.cuda.synchronize()
@@ -40,6 +41,6 @@ for (M, N, K) in shapes:
     refb = dy.float().sum(0)
     e = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
     fl = 2.0 * M * N * K
-    print(f"TN M={M} N={N} K={K}: lock-step " + " ".join(f"{fl/t/1e12:7.1f}" for t in res[0]) + "  ping-pong " + " ".join(f"{fl/t/1e12:7.1f}" for t in res[1]) +
-          f" TF   relerr dW {e(outs[1][0], ref):.2e} (lock-step {e(outs[0][0], ref):.2e})  db {e(outs[1][1], refb):.2e}", flush=True)
+    print(f"TN M={M} N={N} K={K}:" + "".join(f"  tn_pp={v}: " + " ".join(f"{fl/t/1e12:7.1f}" for t in res[v]) for v in PPS) + " TF   relerr dW " +
+          " ".join(f"{e(outs[v][0], ref):.2e}" for v in PPS) + "  db " + " ".join(f"{e(outs[v][1], refb):.2e}" for v in PPS), flush=True)
     del dy, x, ref
