@@ -238,6 +238,9 @@ int meant_rotary_qk(void* qkv, int64_t T, int64_t S, int H, int Dh, int R, const
  * weight -- and keeps its own scale; other Dh take a slow fp32 detour through `workspace`); f32: materialised scores
  * in `workspace`. */
 size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
+/* what meant_attn_fwd alone needs (mask bias, tile flags); meant_attn_ws covers forward and backward (bf16: the backward's row
+ * statistics and, for 256 < S <= 512 at Dh = 64, the single-pass backward's partial-dQ scratch of G*H*64 KiB) */
+size_t meant_attn_fwd_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
 int meant_attn_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H,
                    int Dh, float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
                    void* stream);

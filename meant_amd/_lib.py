@@ -43,6 +43,7 @@ SIGNATURES = {
     "meant_gemm_f32_strided": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _f, _i, _p]),
     "meant_rotary_qk": (_i, [_p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
     "meant_attn_ws": (_sz, [_i64, _i64, _i, _i, _i]),
+    "meant_attn_fwd_ws": (_sz, [_i64, _i64, _i, _i, _i]),
     "meant_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _i, _p, _sz, _p]),
     "meant_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "meant_qkv_proj_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p]),

@@ -182,6 +182,10 @@ extern "C" size_t meant_attn_ws(int64_t G, int64_t S, int H, int Dh, int dtype) 
   return dtype == MEANT_F32 ? attn_f32_ws(G, S, H, Dh) : attn_bf16_ws(G, S, H, Dh);
 }
 
+extern "C" size_t meant_attn_fwd_ws(int64_t G, int64_t S, int H, int Dh, int dtype) {
+  return dtype == MEANT_F32 ? attn_f32_ws(G, S, H, Dh) : attn_bf16_fwd_ws(G, S, H, Dh);
+}
+
 static int attn_check(const char* name, int64_t G, int64_t S, int H, int Dh) {
   MEANT_REQUIRE(G > 0 && S > 0 && H > 0 && Dh > 0, MEANT_ERR_ARG, "%s: bad shape G=%lld S=%lld H=%d Dh=%d", name, (long long)G, (long long)S, H, Dh);
   return MEANT_OK;

@@ -878,6 +878,13 @@ size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh) {
   return 2 * align256(T * 3 * D * 4) + 2 * align256(T * D * 4) + attn_f32_ws(G, S, H, Dh);
 }
 
+// the forward's own workspace: [bias2 | flags | masks] -- neither the backward's delta planes nor the single-pass backward's
+// partial-dQ scratch (1.2 GB at the text shape) belong to it
+size_t attn_bf16_fwd_ws(int64_t G, int64_t S, int H, int Dh) {
+  if (native_dh(Dh)) return ws_bias_bytes(G, S) + ws_flag_bytes(G, S) + ws_mask_bytes(G);
+  return attn_bf16_ws(G, S, H, Dh);
+}
+
 static int cast_async(const void* src, int sd, void* dst, int dd, int64_t n, hipStream_t st) { return meant_cast(src, sd, dst, dd, n, st); }
 
 static int attn_bf16_generic(bool backward, const bf16* qkv, const bf16* o, const bf16* dout, bf16* o_out, float* lse, const float* key_mask,
@@ -918,9 +925,9 @@ int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, i
   int rc = attn_bf16_check("attn_fwd", G, S, H, Dh);
   if (rc) return rc;
   MEANT_REQUIRE(meant_aligned16(qkv) && meant_aligned16(o), MEANT_ERR_ARG, "attn_fwd: 16-byte alignment");
-  MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn_fwd: workspace too small");
+  MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_fwd_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn_fwd: workspace too small");
   const int nt = (int)ceil_div(S, KV_TILE);
-  float* bias2 = (float*)((char*)ws + ws_delta_bytes(G, S, H));
+  float* bias2 = (float*)ws;
   int* flags = (int*)((char*)bias2 + ws_bias_bytes(G, S));
   hipLaunchKernelGGL(attn_prep_mask_kernel, dim3((unsigned)nt, (unsigned)G), dim3(64), 0, stream, key_mask, bias2, flags, (int)S, nt, causal, (unsigned*)nullptr);
   MEANT_LAUNCH_CHECK("attn_prep_mask");

@@ -67,6 +67,7 @@ int attn_bf16_bwd(const bf16* qkv, const bf16* o, const bf16* dout, const float*
                   int64_t G, int64_t S, int H, int Dh, float scale, int causal, RotTables rot, void* ws, size_t ws_bytes,
                   hipStream_t stream);
 size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh);
+size_t attn_bf16_fwd_ws(int64_t G, int64_t S, int H, int Dh);
 // S <= 16: one wave per (group, head) (attn_short.hip); same layouts, statistics and semantics, no workspace
 bool attn_short_ok(int64_t S, int Dh);
 int attn_short_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh, float scale,

@@ -176,6 +176,10 @@ extern "C" int meant_sumsq_f32(const float* x, int64_t n, float* out_accum, void
   if (n == 0) return MEANT_OK;
   int64_t nb = ceil_div(n, 256 * 16);
   if (nb > 2048) nb = 2048;
+  // option `deterministic`: one workgroup, so the sum has ONE order (the per-block float atomics otherwise land in arrival order and
+  // the clip coefficient differs in its last bit from run to run -- enough for a resumed run to leave the original's path: a 1-ulp
+  // difference in an fp32 weight flips the bf16 rounding of a few of them in the next step).  ~1 ms per 100 MB of gradients.
+  if (meant_opt(MEANT_OPT_DETERMINISTIC) != 0) nb = 1;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, n, out_accum);
   MEANT_LAUNCH_CHECK("sumsq_f32");
   return MEANT_OK;

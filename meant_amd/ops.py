@@ -891,7 +891,7 @@ class _QKVAttention(torch.autograd.Function):
         lse = torch.empty((G, num_heads, S, 2), device=x.device, dtype=torch.float32)
         km = _c(key_mask.float()) if key_mask is not None else None
         scale = 1.0 / math.sqrt(Dh * num_heads) if scale is None else float(scale)
-        wsb = lib.meant_attn_ws(G, S, num_heads, Dh, dt)
+        wsb = lib.meant_attn_fwd_ws(G, S, num_heads, Dh, dt)
         ws = torch.empty(max(wsb, 16), device=x.device, dtype=torch.uint8)
         check(lib.meant_attn_fwd(_p(qkv), _p(o), _p(lse), _p(km), G, S, num_heads, Dh, scale, int(causal), dt, _p(ws), wsb,
                                  _stream()), "attn_fwd")
@@ -1494,7 +1494,7 @@ class _AttentionCore(torch.autograd.Function):
         o = torch.empty((G * S, D), device=qkv.device, dtype=qkv.dtype)
         lse = torch.empty((G, H, S, 2), device=qkv.device, dtype=torch.float32)
         km = _c(key_mask.float()) if key_mask is not None else None
-        wsb = lib.meant_attn_ws(G, S, H, Dh, dt)
+        wsb = lib.meant_attn_fwd_ws(G, S, H, Dh, dt)
         ws = torch.empty(max(wsb, 16), device=qkv.device, dtype=torch.uint8)
         check(lib.meant_attn_fwd(_p(q2), _p(o), _p(lse), _p(km), G, S, H, Dh, float(scale), int(causal), dt, _p(ws), wsb, _stream()), "attn_fwd")
         ctx.save_for_backward(q2, o, lse, km)
@@ -1591,7 +1591,7 @@ class _DividedAttention(torch.autograd.Function):
         og = torch.empty((b * G * S, D), device=qkv.device, dtype=qkv.dtype)
         lse = torch.empty((b * G, H, S, 2), device=qkv.device, dtype=torch.float32)
         km = _c(group_mask.float()) if group_mask is not None else None         # [b G, S]
-        wsb = lib.meant_attn_ws(b * G, S, H, Dh, dt)
+        wsb = lib.meant_attn_fwd_ws(b * G, S, H, Dh, dt)
         ws = torch.empty(max(wsb, 16), device=qkv.device, dtype=torch.uint8)
         check(lib.meant_attn_fwd(_p(grouped), _p(og), _p(lse), _p(km), b * G, S, H, Dh, float(scale), 0, dt, _p(ws), wsb, _stream()), "attn_fwd")
         out = gather_rows(og, idx_out).view(b, L, D)                             # row 0 of every sequence: zeros for now

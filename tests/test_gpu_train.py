@@ -46,11 +46,11 @@ def test_optimizer_and_scheduler_resume_continue_identically(dev):
     """checkpoint_train.py:217-219,333-336 / in_loop_train.py:547-567 of the reference save and restore `model.state_dict()`,
     `optimizer.state_dict()` and the scheduler: a FRESH model + TrainStep + CosineWarmRestarts loaded from the three state dicts
     after step 3 (epoch 8, i.e. one epoch past the warm restart at 7) must take the next steps exactly as the original run does.
-    Train mode (the dropout masks are drawn from the torch seed set before every step), deterministic reductions.  "Exactly" is to
-    1e-6: the global-norm sum of the clip is a float-atomic reduction and differs in its last bits between runs (two FRESH runs of
-    this test differ far more after five steps, 1e-3, because AdamW turns the rounding noise of mathematically-zero gradients --
-    the key biases of every attention -- into +-lr steps; a resume takes the moments with it and stays on the original's path).
-    Control: the same resume WITHOUT the optimizer's state lands somewhere else."""
+    Train mode (the dropout masks are drawn from the torch seed set before every step), option `deterministic` (every reduction in
+    one order, including the clip's global-norm sum: with float atomics there the clip coefficient differs in its last bit from run
+    to run, a few fp32 weights then round to a different bf16 value in the next step, and AdamW turns the changed rounding noise of
+    mathematically-zero gradients -- the key biases of every attention -- into fractions of an lr step: 1e-5 after two steps).
+    So "exactly" means bit for bit.  Control: the same resume WITHOUT the optimizer's state lands somewhere else."""
     import meant_amd
     from meant_amd import _lib
     from meant_amd.train import TrainStep, CosineWarmRestarts
@@ -92,7 +92,7 @@ def test_optimizer_and_scheduler_resume_continue_identically(dev):
         assert ts2.opt.step_count == 3 and ts2.opt.lr == sched2.lr_at(8)
         steps(ts2, sched2, 3, 2)
         worst = max((v.float() - want[k].float()).abs().max().item() for k, v in m2.state_dict().items())
-        assert worst <= 1e-6, worst
+        assert worst == 0.0, worst
         m3, ts3, sched3 = make()                             # control: model and scheduler restored, optimizer moments lost
         m3.load_state_dict(saved["model"])
         sched3.load_state_dict(saved["sched"])

@@ -34,6 +34,21 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert meant_amd.lib.meant_version() >= 100          # pure host call, no GPU needed
 
 
+def test_attention_forward_workspace_leaves_out_the_backward_scratch():
+    """the single-pass backward's partial-dQ scratch (G*H*64 KiB for 256 < S <= 512) and the backward's row statistics
+    are not part of what a forward call allocates (pure host arithmetic, no GPU needed)"""
+    import meant_amd
+    lib = meant_amd.lib
+    BF16, F32 = 1, 0
+    G, S, H, Dh = 1536, 512, 12, 64                      # the text shape of the benchmark
+    full, fwd = lib.meant_attn_ws(G, S, H, Dh, BF16), lib.meant_attn_fwd_ws(G, S, H, Dh, BF16)
+    assert full >= G * H * 64 * 1024                     # the scratch is in the backward's size
+    assert fwd < 16 << 20 and fwd < full                 # mask bias + tile flags only
+    assert lib.meant_attn_fwd_ws(G, 196, H, Dh, BF16) <= lib.meant_attn_ws(G, 196, H, Dh, BF16)
+    assert lib.meant_attn_fwd_ws(8, 64, 4, 80, BF16) == lib.meant_attn_ws(8, 64, 4, 80, BF16)     # the fp32 detour needs it all
+    assert lib.meant_attn_fwd_ws(8, 64, 4, 64, F32) == lib.meant_attn_ws(8, 64, 4, 64, F32)
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "meant_amd")):
         for f in files:
