@@ -883,6 +883,9 @@ enum { NTE_PLAIN = 0, NTE_RES, NTE_GELU_PRE, NTE_ROT, NTE_EXT, NTE_GENERIC };
 #ifndef PP_STORE_SC1
 #define PP_STORE_SC1 1
 #endif
+#ifndef PP_ROT_WALK
+#define PP_ROT_WALK 1
+#endif
 #define GAS __attribute__((address_space(1)))
 template <typename T> __device__ __forceinline__ const GAS T* gp(const T* p) { return (const GAS T*)p; }
 template <typename T> __device__ __forceinline__ GAS T* gpw(T* p) { return (GAS T*)p; }
@@ -1224,8 +1227,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256p_kernel(GemmBf16Args a
     vB[p] = (unsigned)(((32 * wave + 8 * p + rl) * a.ldb + (c0 ^ ((p & 1) << 2)) * 8) * 2) + (PP_DMA_IMM ? 3072 - 1024 * p : 0);
   }
   const unsigned lds0 = lds_addr(smem) + wave * 4096;  // this wave's first piece inside slot 0
+  // Rotary mode, sequences of P = S / 256 > 1 row panels (mode bits 16..: P; the launcher checks that P divides the panel count):
+  // the walk takes the panels of one position range after the other (all panels p with p mod P == 0, then == 1, ...) instead of in
+  // memory order.  A tile's epilogue reads the 256 table rows of its positions (98 KB at R = 48); an XCD's 32 workgroups turn its
+  // 4 MiB L2 over every ~3 us, and in memory order the ~3.5 panels an XCD has in flight cover all position ranges, so a table row is
+  // touched again only every ~3 us per (range, section) -- it was evicted every time: 1.86 GB per launch of table rows from beyond L2
+  // at (786432, 2304, 768), HBM-side traffic 2.05x the algorithmic bytes (profiles/r04_nt256p_hbm_traffic.json).  With one range
+  // at a time the working set halves and every tile touches it.
+  const int rotP = MODE == NTE_ROT ? (mode >> 16) : 1;
+  const int rotQ = MODE == NTE_ROT && rotP > 1 ? ntm / rotP : 1;
   auto origin = [&](int t, const bf16*& pa, const bf16*& pb, int64_t& m0, int64_t& n0) {
-    const int tm = t / ntn, tn = t - tm * ntn;
+    int tm = t / ntn;
+    const int tn = t - tm * ntn;
+    if (MODE == NTE_ROT && rotP > 1) { const int r = tm / rotQ; tm = (tm - r * rotQ) * rotP + r; }
     m0 = (int64_t)tm * B2;
     m0 = m0 + B2 <= a.M ? m0 : a.M - B2;               // ragged M: the last row tile is moved up to END at row M (see the launcher)
     n0 = (int64_t)tn * B2;
@@ -2096,6 +2110,9 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
       if (meant_opt(MEANT_OPT_NT_PP) != 0 && a.K >= 4 * BK) {   // ping-pong form: the two waves of a SIMD alternate between MFMA and load halves
         const int ppopt = meant_opt(MEANT_OPT_NT_PP);
         const int dynmode = dynmode0 | ((ppopt & 8) ? 0x100 : 0);   // lab, bit 3: staggered start
+        // rotary mode: panels of one position range after the other (see the kernel's `origin`); PP_ROT_WALK=0 builds without it
+        int rotP = 0;
+        if (a.rot_qa && PP_ROT_WALK && a.rot_S % B2 == 0 && a.rot_S / B2 > 1 && a.rot_S / B2 < 256 && a.M % B2 == 0 && ntm2 % (a.rot_S / B2) == 0) rotP = (int)(a.rot_S / B2);
         // the epilogue's options as a template parameter (see nt256_wave_epilogue): the combinations the models run get straight-line
         // code, anything else the generic instantiation with run-time flags
         const bool act = (a.epilogue & (MEANT_EPI_GELU | MEANT_EPI_SIGMOID)) != 0;
@@ -2106,7 +2123,7 @@ int gemm_bf16_nt_launch(const GemmBf16Args& a, hipStream_t stream) {
         else if (a.residual && !a.preact && !act) emode = NTE_RES;
         else if (!a.residual && a.preact && (a.epilogue & MEANT_EPI_GELU) && !(a.epilogue & MEANT_EPI_SIGMOID)) emode = NTE_GELU_PRE;
         MEANT_REQUIRE(emode >= 0, MEANT_ERR_UNSUPPORTED, "gemm_bf16_nt: rotary epilogue with residual / activation / preact");
-#define PP_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_bf16_nt256p_kernel<MODE_>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode)
+#define PP_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_bf16_nt256p_kernel<MODE_>), g3, b3, RING * T2_BYTES, stream, a, (int)ntm2, (int)ntn2, sched, dynmode | (rotP << 16))
         switch (emode) {
           case NTE_PLAIN: PP_LAUNCH(NTE_PLAIN); break;
           case NTE_RES: PP_LAUNCH(NTE_RES); break;
