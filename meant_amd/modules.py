@@ -148,9 +148,12 @@ class RotaryEmbedding(nn.Module):
             freqs = torch.ones(num_freqs).float()
         else:
             raise ValueError(f'unknown modality {freqs_for}')
-        if learned_freq:
-            raise NotImplementedError("meant_amd.RotaryEmbedding: learned_freq is not on the MEANT hot path")
-        self.freqs = nn.Parameter(freqs, requires_grad=False)
+        # learned_freq (rotary_embedding_torch.py:67,85: `freqs` is then a trainable Parameter; no reference model sets it): the fused
+        # kernels rotate inside the projection GEMM's epilogue and undo it inside the attention backward, neither of which returns a
+        # gradient for the tables -- an attention module whose rotary has learned frequencies therefore takes the UNFUSED route
+        # (`learned_rotary_attention` below: projection GEMM, rotation as differentiable tensor ops on the device, attention core without tables)
+        self.learned_freq = bool(learned_freq)
+        self.freqs = nn.Parameter(freqs, requires_grad=self.learned_freq)
         self.use_xpos = use_xpos
         self.scale_base = xpos_scale_base
         if use_xpos:
@@ -167,6 +170,20 @@ class RotaryEmbedding(nn.Module):
     @property
     def rot_dim(self) -> int:
         return 2 * self.freqs.numel()
+
+    def tables_autograd(self, seq_len: int) -> tuple:
+        """the same four tables as differentiable functions of `freqs`, on the parameter's device (learned_freq)"""
+        f = self.freqs.float()
+        pos = torch.arange(seq_len, device=f.device, dtype=f.dtype)
+        ang = torch.repeat_interleave(pos[:, None] * f[None, :], 2, dim=-1)
+        cos, sin = ang.cos(), ang.sin()
+        if not self.use_xpos:
+            return cos, sin, cos, sin
+        power = (torch.arange(seq_len, device=f.device) - seq_len // 2) / self.scale_base
+        s = self.scale.float()[None, :] ** power[:, None]
+        s = torch.cat((s, s), dim=-1)
+        si = s ** -1
+        return cos * s, sin * s, cos * si, sin * si
 
     def tables(self, seq_len: int, device) -> tuple:
         """(qa, qb, ka, kb) float32 [S, R] on `device`: out = t*a + rot(t)*b."""
@@ -195,6 +212,35 @@ class RotaryEmbedding(nn.Module):
         return t
 
 
+def _rotate_pairs(t, a, b):
+    """t [G, S, H, Dh]; a, b [S, R]: out[..., :R] = t * a + rot(t) * b with rot(t)[2j] = -t[2j+1], rot(t)[2j+1] = t[2j]
+    (what meant_rotary_qk / the projection GEMM's epilogue compute), in fp32, rounded back to t's dtype; columns past R pass through"""
+    R = a.shape[1]
+    tr = t[..., :R].float()
+    pr = tr.reshape(*tr.shape[:-1], R // 2, 2)
+    rot = torch.stack((-pr[..., 1], pr[..., 0]), dim=-1).reshape(tr.shape)
+    out = tr * a[None, :, None, :] + rot * b[None, :, None, :]
+    return torch.cat((out.to(t.dtype), t[..., R:]), dim=-1)
+
+
+def learned_rotary_attention(x, mod, rot: RotaryEmbedding, key_mask, causal: bool, pre=None):
+    """softmax((rot q)(rot k)^T / sqrt(dim) [+ mask]) v for a rotary embedding with LEARNED frequencies: the q|k|v projection as one GEMM
+    (ops.linear), the rotation as tensor ops whose tables carry the gradient to `rot.freqs`, the attention core (HIP) on the rotated
+    buffer without tables.  `mod` holds the q / v / k Linears under the reference's names (the one called `v` produces the keys)."""
+    G, S, d = x.shape
+    H = mod.num_heads
+    wqkv = torch.cat([mod.q.weight, mod.v.weight, mod.k.weight], dim=0)
+    bqkv = torch.cat([mod.q.bias, mod.v.bias, mod.k.bias], dim=0)
+    if pre is not None:
+        wqkv, bqkv = ops.compose_linear(pre.weight, pre.bias, wqkv, bqkv)
+    D = wqkv.shape[0] // 3
+    qkv = ops.linear(x.reshape(G * S, d), wqkv, bqkv).view(G, S, 3, H, D // H)
+    qa, qb, ka, kb = rot.tables_autograd(S)
+    q, k = _rotate_pairs(qkv[:, :, 0], qa, qb), _rotate_pairs(qkv[:, :, 1], ka, kb)
+    packed = torch.stack((q, k, qkv[:, :, 2]), dim=2).reshape(G * S, 3 * D)
+    return ops.attention_core(packed, G, S, H, 1.0 / math.sqrt(D), None, causal, key_mask).view(G, S, D)
+
+
 # ------------------------------------------------------------------------------------------
 class attention(nn.Module):
     """meant/attention.py:11-62: MHA over patches, pixel rotary on q,k, no mask, scale 1/sqrt(dim).
@@ -215,6 +261,8 @@ class attention(nn.Module):
 
     def core(self, x, pre=None):
         """pre: an nn.Linear that the caller would have applied to x right before this module (composed into q/k/v)"""
+        if self.pos_emb is not None and getattr(self.pos_emb, 'learned_freq', False):
+            return learned_rotary_attention(x, self, self.pos_emb, None, bool(self.mask), pre)
         tables = self.pos_emb.tables(x.shape[1], x.device) if self.pos_emb is not None else None
         prew = (pre.weight, pre.bias) if pre is not None else None
         return ops.qkv_attention(x, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,
@@ -245,6 +293,8 @@ class xPosAttention(nn.Module):
         self.k = Linear(self.dim, self.Dh * self.num_heads)
 
     def core(self, x, attention_mask=None, pre=None):
+        if getattr(self.xPos, 'learned_freq', False):
+            return learned_rotary_attention(x, self, self.xPos, attention_mask, bool(self.mask), pre)
         tables = self.xPos.tables(x.shape[1], x.device)
         prew = (pre.weight, pre.bias) if pre is not None else None
         return ops.qkv_attention(x, self.q.weight, self.q.bias, self.v.weight, self.v.bias, self.k.weight, self.k.bias,

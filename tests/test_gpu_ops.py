@@ -289,6 +289,44 @@ def test_attention_modules_vs_oracle(M, O, dev, dtype, kind, G, S, H, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("kind,G,S,H,d", [("pixel", 2, 100, 2, 128), ("xpos", 3, 96, 2, 128), ("xpos", 2, 300, 4, 384)])
+def test_attention_with_learned_rotary_frequencies(M, O, dev, dtype, kind, G, S, H, d):
+    """RotaryEmbedding(learned_freq=True) (rotary_embedding_torch.py:67,85): `freqs` trains.  The module then takes the unfused
+    route (projection GEMM, rotation as tensor ops, attention core without tables); outputs, input gradient, every parameter
+    gradient AND d loss / d freqs against the oracle, whose tables are plain differentiable functions of its `freqs`."""
+    if kind == "pixel":
+        ref = O.attention(H, d, O.RotaryTable(math.floor(d / H / 2), "pixel"))
+        hip = M.attention(H, d, M.RotaryEmbedding(dim=math.floor(d / H / 2), freqs_for="pixel", learned_freq=True))
+    else:
+        ref = O.xPosAttention(H, d, O.RotaryTable(48, "lang", use_xpos=True))
+        hip = M.xPosAttention(H, d, M.RotaryEmbedding(dim=48, use_xpos=True, learned_freq=True))
+    ref, hip = pair(ref, hip, 977, dev)
+    rot_ref = ref.pos_emb if kind == "pixel" else ref.xPos
+    rot_hip = hip.pos_emb if kind == "pixel" else hip.xPos
+    rot_ref.freqs.requires_grad_(True)
+    assert rot_hip.freqs.requires_grad and rot_hip.learned_freq
+    rs = np.random.RandomState(S + d)
+    x = t(rs.standard_normal((G, S, d)).astype("float32"))
+    dy = t(rs.standard_normal((G, S, d)).astype("float32"))
+    mask = torch.ones(G, S)
+    if kind == "xpos":
+        mask[0, S // 2:] = 0
+    xr = x.to(dtype).float().clone().requires_grad_()
+    yr = ref(xr, mask) if kind == "xpos" else ref(xr)
+    yr.backward(dy.to(dtype).float())
+    xh = x.to(dev).to(dtype).requires_grad_()
+    yh = hip(xh, mask.to(dev)) if kind == "xpos" else hip(xh)
+    yh.backward(dy.to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert_close(yh, yr, tol["out"] * (1 if dtype == torch.float32 else 4), "y")
+    assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+    compare_param_grads(ref, hip, dtype, kind + " learned_freq")
+    gf, gr = rot_hip.freqs.grad, rot_ref.freqs.grad
+    assert gf is not None and gr is not None and gr.abs().max().item() > 0
+    assert_grad_close(gf, gr, tol["gelem"], "d freqs")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("H,d", [(2, 128), (2, 192), (1, 128)], ids=["dh64", "dh96", "dh128"])
 def test_text_attention_padding_patterns(M, O, dev, dtype, H, d):
     """the bf16 kernels skip key tiles that are all padding when key 0 is live; every pattern that does or does not
