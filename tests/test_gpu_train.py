@@ -357,6 +357,19 @@ def test_bench_other_configs_print_the_contract_line(dev, model, batch):
     assert res["ms_per_step_median"] > 0 and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(res["roofline"])
 
 
+def test_bench_fp32_tier_field_and_one_rank_rccl_line(dev):
+    """`--fp32-batch n` adds the fp32 tier's own throughput to the line (the tier north_star's 1e-3 tolerance is stated
+    for); `MEANT_REDUCE_ALWAYS=1` runs the step with a one-rank RCCL group -- the reducer's launch stream and RCCL's stream beside
+    the step's own, the rehearsal of a multi-GPU launch one GPU allows -- and must come out as the same contract line"""
+    res = _run_bench(["--batch-per-gpu", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--fp32-batch", "1"], {})
+    f = res["fp32_tier"]
+    assert f["batch_per_gpu"] == 1 and f["ms_per_step"] > 0 and np.isfinite(f["samples_per_s"]) and f["samples_per_s"] > 0
+    assert 0 < f["whole_step_f32_matrix_frac"] < 1
+    red = _run_bench(["--batch-per-gpu", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"MEANT_REDUCE_ALWAYS": "1"})
+    assert red["n_gpus"] == 1 and red["config"]["grad_allreduce"] is True and np.isfinite(red["value"]) and red["value"] > 0
+    assert res["config"]["grad_allreduce"] is False
+
+
 # ---- gradient sinks and shared parameters (ADVICE r2) ------------------------------------------------------------------------
 _TIED_TWO_RANKS = r"""
 import os, sys, torch, torch.distributed as dist
