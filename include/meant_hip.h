@@ -244,6 +244,20 @@ size_t meant_attn_fwd_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
 int meant_attn_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H,
                    int Dh, float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
                    void* stream);
+/* Attention with dropout ON THE SCORE MATRIX, where meant/xPosAttention.py:59 has it (`scores = self.dropout(scores)`: after the
+ * causal fill and the key-padding term, before the softmax; p = 0 in every reference model): a dropped score becomes 0 -- also
+ * that of a masked position, which thereby becomes visible --, a kept one is divided by 1 - drop_p.  Score (g, h, i, j) is kept iff
+ * the counter-based uniform of (seed, ((g H + h) S + i) S + j) is >= drop_p; forward and backward must be given the same
+ * (drop_p, seed).  Same buffers and layouts as meant_attn_fwd / meant_attn_bwd; q and k arrive rotated (meant_rotary_qk) and dqkv
+ * is the gradient w.r.t. that rotated buffer (apply meant_rotary_qk with transpose = 1 afterwards).  Materialised scores (the
+ * fp32 core; bf16 through fp32 copies in the workspace): correct, not fast. */
+size_t meant_attn_drop_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
+int meant_attn_drop_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
+                        float scale, int causal, float drop_p, uint64_t seed, int dtype, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int meant_attn_drop_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask, void* dqkv,
+                        int64_t G, int64_t S, int H, int Dh, float scale, int causal, float drop_p, uint64_t seed,
+                        int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* dqkv: act [G*S, 3*H*Dh] (every element written); do_: act [G*S, H*Dh].
  * If the rotary tables qa,qb,ka,kb (float [S, R], as in meant_rotary_qk) are given, dq and dk are returned
  * already pulled back through the rotation (the adjoint of meant_rotary_qk), i.e. dqkv is the gradient of

@@ -44,6 +44,9 @@ SIGNATURES = {
     "meant_rotary_qk": (_i, [_p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
     "meant_attn_ws": (_sz, [_i64, _i64, _i, _i, _i]),
     "meant_attn_fwd_ws": (_sz, [_i64, _i64, _i, _i, _i]),
+    "meant_attn_drop_ws": (_sz, [_i64, _i64, _i, _i, _i]),
+    "meant_attn_drop_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _f, _u64, _i, _p, _sz, _p]),
+    "meant_attn_drop_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _f, _u64, _i, _p, _sz, _p]),
     "meant_attn_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _i, _p, _sz, _p]),
     "meant_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "meant_qkv_proj_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p]),

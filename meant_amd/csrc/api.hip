@@ -204,6 +204,45 @@ extern "C" int meant_attn_fwd(const void* qkv, void* o, float* lse, const float*
   return MEANT_ERR_ARG;
 }
 
+// ---- attention with dropout on the score matrix (meant/xPosAttention.py:59) ----
+extern "C" size_t meant_attn_drop_ws(int64_t G, int64_t S, int H, int Dh, int dtype) { return attn_drop_ws(G, S, H, Dh, dtype); }
+
+extern "C" int meant_attn_drop_fwd(const void* qkv, void* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
+                                   float scale, int causal, float drop_p, uint64_t seed, int dtype, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  MEANT_REQUIRE(qkv && o && lse, MEANT_ERR_ARG, "attn_drop_fwd: null pointer");
+  MEANT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MEANT_ERR_ARG, "attn_drop_fwd: drop_p = %g is not in [0, 1)", (double)drop_p);
+  int rc = attn_check("attn_drop_fwd", G, S, H, Dh);
+  if (rc) return rc;
+  MEANT_REQUIRE(workspace && workspace_bytes >= attn_drop_ws(G, S, H, Dh, dtype), MEANT_ERR_WORKSPACE, "attn_drop_fwd: workspace too small");
+  if (dtype == MEANT_F32)
+    return attn_f32_fwd((const float*)qkv, (float*)o, lse, key_mask, G, S, H, Dh, scale, causal, workspace, workspace_bytes, (hipStream_t)stream,
+                        drop_p, seed);
+  if (dtype == MEANT_BF16)
+    return attn_drop_bf16(false, (const bf16*)qkv, nullptr, nullptr, (bf16*)o, lse, key_mask, nullptr, G, S, H, Dh, scale, causal, drop_p, seed,
+                          workspace, workspace_bytes, (hipStream_t)stream);
+  meant_set_error("attn_drop_fwd: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}
+
+extern "C" int meant_attn_drop_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask, void* dqkv,
+                                   int64_t G, int64_t S, int H, int Dh, float scale, int causal, float drop_p, uint64_t seed, int dtype,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  MEANT_REQUIRE(qkv && o && do_ && lse && dqkv, MEANT_ERR_ARG, "attn_drop_bwd: null pointer");
+  MEANT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MEANT_ERR_ARG, "attn_drop_bwd: drop_p = %g is not in [0, 1)", (double)drop_p);
+  int rc = attn_check("attn_drop_bwd", G, S, H, Dh);
+  if (rc) return rc;
+  MEANT_REQUIRE(workspace && workspace_bytes >= attn_drop_ws(G, S, H, Dh, dtype), MEANT_ERR_WORKSPACE, "attn_drop_bwd: workspace too small");
+  if (dtype == MEANT_F32)
+    return attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)do_, lse, key_mask, (float*)dqkv, G, S, H, Dh, scale, causal, workspace,
+                        workspace_bytes, (hipStream_t)stream, drop_p, seed);
+  if (dtype == MEANT_BF16)
+    return attn_drop_bf16(true, (const bf16*)qkv, (const bf16*)o, (const bf16*)do_, nullptr, const_cast<float*>(lse), key_mask, (bf16*)dqkv, G, S, H, Dh, scale, causal,
+                          drop_p, seed, workspace, workspace_bytes, (hipStream_t)stream);
+  meant_set_error("attn_drop_bwd: unknown dtype %d", dtype);
+  return MEANT_ERR_ARG;
+}
+
 extern "C" int meant_attn_bwd(const void* qkv, const void* o, const void* do_, const float* lse, const float* key_mask, void* dqkv,
                               int64_t G, int64_t S, int H, int Dh, float scale, int causal, const float* qa, const float* qb,
                               const float* ka, const float* kb, int R, int dtype, void* workspace, size_t workspace_bytes,

@@ -874,8 +874,7 @@ static size_t ws_mask_bytes(int64_t G) { return align256((size_t)G * 2 * sizeof(
 
 size_t attn_bf16_ws(int64_t G, int64_t S, int H, int Dh) {
   if (native_dh(Dh)) return ws_delta_bytes(G, S, H) + ws_bias_bytes(G, S) + ws_flag_bytes(G, S) + ws_mask_bytes(G) + attn_bwd1_ws(G, S, H, Dh);
-  const size_t T = (size_t)G * S, D = (size_t)H * Dh;
-  return 2 * align256(T * 3 * D * 4) + 2 * align256(T * D * 4) + attn_f32_ws(G, S, H, Dh);
+  return 2 * align256((size_t)G * S * 3 * H * Dh * 4) + 2 * align256((size_t)G * S * H * Dh * 4) + attn_f32_ws(G, S, H, Dh);
 }
 
 // the forward's own workspace: [bias2 | flags | masks] -- neither the backward's delta planes nor the single-pass backward's
@@ -887,11 +886,16 @@ size_t attn_bf16_fwd_ws(int64_t G, int64_t S, int H, int Dh) {
 
 static int cast_async(const void* src, int sd, void* dst, int dd, int64_t n, hipStream_t st) { return meant_cast(src, sd, dst, dd, n, st); }
 
+static size_t generic_ws(int64_t G, int64_t S, int H, int Dh) {
+  const size_t T = (size_t)G * S, D = (size_t)H * Dh;
+  return 2 * align256(T * 3 * D * 4) + 2 * align256(T * D * 4) + attn_f32_ws(G, S, H, Dh);
+}
+
 static int attn_bf16_generic(bool backward, const bf16* qkv, const bf16* o, const bf16* dout, bf16* o_out, float* lse, const float* key_mask,
                              bf16* dqkv, int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes,
-                             hipStream_t stream) {
+                             hipStream_t stream, float drop_p = 0.f, uint64_t seed = 0) {
   meant_route_hit(ROUTE_ATTN_GENERIC);
-  MEANT_REQUIRE(ws && ws_bytes >= attn_bf16_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn(bf16, Dh=%d): workspace too small", Dh);
+  MEANT_REQUIRE(ws && ws_bytes >= generic_ws(G, S, H, Dh), MEANT_ERR_WORKSPACE, "attn(bf16, Dh=%d): workspace too small", Dh);
   const int64_t T = G * S, D = (int64_t)H * Dh;
   char* w = (char*)ws;
   float* qkv32 = (float*)w; w += align256((size_t)T * 3 * D * 4);
@@ -902,13 +906,23 @@ static int attn_bf16_generic(bool backward, const bf16* qkv, const bf16* o, cons
   int rc;
   if ((rc = cast_async(qkv, MEANT_BF16, qkv32, MEANT_F32, T * 3 * D, stream))) return rc;
   if (!backward) {
-    if ((rc = attn_f32_fwd(qkv32, o32, lse, key_mask, G, S, H, Dh, scale, causal, w, rest, stream))) return rc;
+    if ((rc = attn_f32_fwd(qkv32, o32, lse, key_mask, G, S, H, Dh, scale, causal, w, rest, stream, drop_p, seed))) return rc;
     return cast_async(o32, MEANT_F32, o_out, MEANT_BF16, T * D, stream);
   }
   if ((rc = cast_async(dout, MEANT_BF16, do32, MEANT_F32, T * D, stream))) return rc;
-  if ((rc = attn_f32_bwd(qkv32, o32, do32, lse, key_mask, dqkv32, G, S, H, Dh, scale, causal, w, rest, stream))) return rc;
+  if ((rc = attn_f32_bwd(qkv32, o32, do32, lse, key_mask, dqkv32, G, S, H, Dh, scale, causal, w, rest, stream, drop_p, seed))) return rc;
   (void)o;
   return cast_async(dqkv32, MEANT_F32, dqkv, MEANT_BF16, T * 3 * D, stream);
+}
+
+size_t attn_drop_ws(int64_t G, int64_t S, int H, int Dh, int dtype) {
+  return dtype == MEANT_F32 ? attn_f32_ws(G, S, H, Dh) : generic_ws(G, S, H, Dh);
+}
+
+int attn_drop_bf16(bool backward, const bf16* qkv, const bf16* o, const bf16* dout, bf16* o_out, float* lse, const float* key_mask, bf16* dqkv,
+                   int64_t G, int64_t S, int H, int Dh, float scale, int causal, float drop_p, uint64_t seed, void* ws, size_t ws_bytes,
+                   hipStream_t stream) {
+  return attn_bf16_generic(backward, qkv, o, dout, o_out, lse, key_mask, dqkv, G, S, H, Dh, scale, causal, ws, ws_bytes, stream, drop_p, seed);
 }
 
 static int attn_bf16_check(const char* name, int64_t G, int64_t S, int H, int Dh) {

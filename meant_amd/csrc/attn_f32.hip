@@ -8,9 +8,13 @@
 namespace {
 
 // one wave per score row.  mode 0: compute (max, log-sum), write P.  mode 1: stats given, write P.
+// drop_p > 0: dropout ON THE SCORES, where meant/xPosAttention.py:59 has it -- after the causal fill and the padding term, before the
+// softmax: a dropped score becomes 0 (also one of a masked position, which thereby becomes visible with weight exp(0 - max)), a kept
+// one is divided by 1 - p.  The keep decision of score (g, h, i, j) is hash_uniform(seed, ((g H + h) S + i) S + j) >= p, the same
+// in the backward.  Every column is then live, so the causal shortcut (columns <= i only) is off.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ sc, float* __restrict__ lse,
                                                             const float* __restrict__ key_mask, int64_t g0, int64_t nrows,
-                                                            int S, int H, int causal, int mode) {
+                                                            int S, int H, int causal, int mode, float drop_p, uint64_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;         // row = ((g_local*H + h)*S + i)
   if (row >= nrows) return;
@@ -20,12 +24,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   float* p = sc + row * S;
   const float* km = key_mask ? key_mask + g * S : nullptr;
   const int jend = causal ? i + 1 : S;
+  const bool drop = drop_p > 0.f;
+  const int jlive = drop ? S : jend;                           // columns that can carry weight
+  const float keep_scale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint64_t rbase = (((uint64_t)g * H + (uint64_t)(gh % H)) * (uint64_t)S + (uint64_t)i) * (uint64_t)S;
+  auto score = [&](int j) {
+    float v = -INFINITY;
+    if (j < jend) {
+      v = p[j];
+      if (km) v += (1.0f - km[j]) * -1e9f;
+    }
+    if (drop) v = hash_uniform(seed, rbase + (uint64_t)j) < drop_p ? 0.f : v * keep_scale;
+    return v;
+  };
   float m = -INFINITY;
-  for (int j = lane; j < jend; j += 64) {
-    float v = p[j];
-    if (km) v += (1.0f - km[j]) * -1e9f;
-    m = fmaxf(m, v);
-  }
+  for (int j = lane; j < jlive; j += 64) m = fmaxf(m, score(j));
   // the row statistics are kept as the pair (max, log-sum): with the reference's additive -1e9 padding
   // term a fully padded row has max ~ -1e9, where a single float max+log(sum) would lose the log(sum).
   float logl;
@@ -33,11 +46,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   if (mode == 0) {
     m = wave_max(m);
     float s = 0.f;
-    for (int j = lane; j < jend; j += 64) {
-      float v = p[j];
-      if (km) v += (1.0f - km[j]) * -1e9f;
-      s += __expf(v - m);
-    }
+    for (int j = lane; j < jlive; j += 64) s += __expf(score(j) - m);
     s = wave_sum(s);
     logl = __logf(s);
     if (lane == 0) { lp[0] = m; lp[1] = logl; }
@@ -45,20 +54,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
     m = lp[0];
     logl = lp[1];
   }
-  for (int j = lane; j < S; j += 64) {
-    float v = 0.f;
-    if (j < jend) {
-      v = p[j];
-      if (km) v += (1.0f - km[j]) * -1e9f;
-      v = __expf((v - m) - logl);
-    }
-    p[j] = v;
-  }
+  for (int j = lane; j < S; j += 64) p[j] = j < jlive ? __expf((score(j) - m) - logl) : 0.f;
 }
 
-// dS = P * (dP - rowsum(P * dP)) * scale, in place on dP
-__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, int64_t nrows,
-                                                                int S, float scale) {
+// dS = P * (dP - rowsum(P * dP)) * scale, in place on dP; with dropout on the scores the gradient of a dropped score is zero and that of
+// a kept one carries the 1 / (1 - p)
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, int64_t g0, int64_t nrows,
+                                                                int S, int H, float scale, float drop_p, uint64_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= nrows) return;
@@ -67,7 +69,15 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
   float dot = 0.f;
   for (int j = lane; j < S; j += 64) dot += p[j] * d[j];
   dot = wave_sum(dot);
-  for (int j = lane; j < S; j += 64) d[j] = p[j] * (d[j] - dot) * scale;
+  const bool drop = drop_p > 0.f;
+  const float keep_scale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const int64_t gh = row / S;
+  const uint64_t rbase = (((uint64_t)(g0 + gh / H) * H + (uint64_t)(gh % H)) * (uint64_t)S + (uint64_t)(row % S)) * (uint64_t)S;
+  for (int j = lane; j < S; j += 64) {
+    float v = p[j] * (d[j] - dot) * scale;
+    if (drop) v = hash_uniform(seed, rbase + (uint64_t)j) < drop_p ? 0.f : v * keep_scale;
+    d[j] = v;
+  }
 }
 
 inline int64_t chunk_groups(int64_t G, int64_t S, int H, size_t ws_bytes, int nbuf) {
@@ -91,7 +101,7 @@ size_t attn_f32_ws(int64_t G, int64_t S, int H, int Dh) {
 }
 
 int attn_f32_fwd(const float* qkv, float* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
-                 float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
+                 float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream, float drop_p, uint64_t seed) {
   MEANT_REQUIRE(ws, MEANT_ERR_WORKSPACE, "attn_f32_fwd: workspace required");
   const int64_t cg = chunk_groups(G, S, H, ws_bytes, 1);
   MEANT_REQUIRE(cg >= 1, MEANT_ERR_WORKSPACE, "attn_f32_fwd: workspace too small for one group");
@@ -111,7 +121,7 @@ int attn_f32_fwd(const float* qkv, float* o, float* lse, const float* key_mask, 
     if (rc) return rc;
     const int64_t nrows = ng * H * S;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, stream, sc, lse, key_mask, g0, nrows,
-                       (int)S, H, causal, 0);
+                       (int)S, H, causal, 0, drop_p, seed);
     MEANT_LAUNCH_CHECK("attn_f32_fwd/softmax");
     GemmF32Args b{};
     b.A = sc; b.B = base + 2 * D; b.C = o + g0 * S * D;
@@ -127,7 +137,8 @@ int attn_f32_fwd(const float* qkv, float* o, float* lse, const float* key_mask, 
 }
 
 int attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, const float* key_mask, float* dqkv,
-                 int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream) {
+                 int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream, float drop_p,
+                 uint64_t seed) {
   (void)o;
   MEANT_REQUIRE(ws, MEANT_ERR_WORKSPACE, "attn_f32_bwd: workspace required");
   const int64_t cg = chunk_groups(G, S, H, ws_bytes, 2);
@@ -158,11 +169,12 @@ int attn_f32_bwd(const float* qkv, const float* o, const float* dout, const floa
     int rc;
     if ((rc = gemm(q, sQ, k, sQt, P, sS, S, S, Dh, scale))) return rc;                 // scores
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, stream, P, const_cast<float*>(lse),
-                       key_mask, g0, nrows, (int)S, H, causal, 1);                      // P = exp(scores - lse)
+                       key_mask, g0, nrows, (int)S, H, causal, 1, drop_p, seed);        // P = exp(scores - lse)
     MEANT_LAUNCH_CHECK("attn_f32_bwd/softmax");
     if ((rc = gemm(P, sSt, dO, sO, dq + 2 * D, sQ, S, Dh, S, 1.f))) return rc;          // dV = P^T dO
     if ((rc = gemm(dO, sO, v, sQt, dP, sS, S, S, Dh, 1.f))) return rc;                  // dP = dO V^T
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, stream, P, dP, nrows, (int)S, scale);
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, stream, P, dP, g0, nrows, (int)S, H, scale,
+                       drop_p, seed);
     MEANT_LAUNCH_CHECK("attn_f32_bwd/softmax_bwd");
     if ((rc = gemm(dP, sS, k, sQ, dq, sQ, S, Dh, S, 1.f))) return rc;                   // dQ = dS K
     if ((rc = gemm(dP, sSt, q, sQ, dq + D, sQ, S, Dh, S, 1.f))) return rc;              // dK = dS^T Q

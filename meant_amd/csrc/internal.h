@@ -55,9 +55,15 @@ int colsum_launch(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, 
 
 // attention cores
 int attn_f32_fwd(const float* qkv, float* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
-                 float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+                 float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream, float drop_p = 0.f, uint64_t seed = 0);
 int attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, const float* key_mask, float* dqkv,
-                 int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);
+                 int64_t G, int64_t S, int H, int Dh, float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream, float drop_p = 0.f,
+                 uint64_t seed = 0);
+// dropout on the score matrix (meant/xPosAttention.py:59): the materialised fp32 core for both dtypes (bf16 through fp32 copies in `ws`)
+size_t attn_drop_ws(int64_t G, int64_t S, int H, int Dh, int dtype);
+int attn_drop_bf16(bool backward, const bf16* qkv, const bf16* o, const bf16* dout, bf16* o_out, float* lse, const float* key_mask, bf16* dqkv,
+                   int64_t G, int64_t S, int H, int Dh, float scale, int causal, float drop_p, uint64_t seed, void* ws, size_t ws_bytes,
+                   hipStream_t stream);
 size_t attn_f32_ws(int64_t G, int64_t S, int H, int Dh);
 int attn_bf16_fwd(const bf16* qkv, bf16* o, float* lse, const float* key_mask, int64_t G, int64_t S, int H, int Dh,
                   float scale, int causal, void* ws, size_t ws_bytes, hipStream_t stream);

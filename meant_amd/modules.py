@@ -241,6 +241,28 @@ def learned_rotary_attention(x, mod, rot: RotaryEmbedding, key_mask, causal: boo
     return ops.attention_core(packed, G, S, H, 1.0 / math.sqrt(D), None, causal, key_mask).view(G, S, D)
 
 
+def score_dropout_attention(x, mod, rot: RotaryEmbedding, key_mask, causal: bool, p: float, seed: int, pre=None):
+    """xPosAttention with droput > 0 in train mode (meant/xPosAttention.py:59 drops SCORES, after the masks and before the softmax):
+    the q|k|v projection as one GEMM, then the materialised attention core with the dropout inside (ops.attention_core_score_dropout),
+    rotary by tables as everywhere else.  With learned rotary frequencies the rotation is done here, differentiably."""
+    G, S, d = x.shape
+    H = mod.num_heads
+    wqkv = torch.cat([mod.q.weight, mod.v.weight, mod.k.weight], dim=0)
+    bqkv = torch.cat([mod.q.bias, mod.v.bias, mod.k.bias], dim=0)
+    if pre is not None:
+        wqkv, bqkv = ops.compose_linear(pre.weight, pre.bias, wqkv, bqkv)
+    D = wqkv.shape[0] // 3
+    qkv = ops.linear(x.reshape(G * S, d), wqkv, bqkv)
+    tables = None
+    if rot is not None and getattr(rot, 'learned_freq', False):
+        q5 = qkv.view(G, S, 3, H, D // H)
+        qa, qb, ka, kb = rot.tables_autograd(S)
+        qkv = torch.stack((_rotate_pairs(q5[:, :, 0], qa, qb), _rotate_pairs(q5[:, :, 1], ka, kb), q5[:, :, 2]), dim=2).reshape(G * S, 3 * D)
+    elif rot is not None:
+        tables = rot.tables(S, x.device)
+    return ops.attention_core_score_dropout(qkv, G, S, H, 1.0 / math.sqrt(D), p, seed, tables, causal, key_mask).view(G, S, D)
+
+
 # ------------------------------------------------------------------------------------------
 class attention(nn.Module):
     """meant/attention.py:11-62: MHA over patches, pixel rotary on q,k, no mask, scale 1/sqrt(dim).
@@ -293,6 +315,8 @@ class xPosAttention(nn.Module):
         self.k = Linear(self.dim, self.Dh * self.num_heads)
 
     def core(self, x, attention_mask=None, pre=None):
+        if self.training and self.dropout.p > 0:              # xPosAttention.py:59: dropout on the SCORES (no reference model sets it)
+            return score_dropout_attention(x, self, self.xPos, attention_mask, bool(self.mask), float(self.dropout.p), _seed(), pre)
         if getattr(self.xPos, 'learned_freq', False):
             return learned_rotary_attention(x, self, self.xPos, attention_mask, bool(self.mask), pre)
         tables = self.xPos.tables(x.shape[1], x.device)
@@ -301,8 +325,6 @@ class xPosAttention(nn.Module):
                                  tables, attention_mask, bool(self.mask), self.num_heads, pre=prew)
 
     def forward(self, input, attention_mask=None):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("meant_amd.xPosAttention: dropout on the score matrix (droput>0) is not supported")
         return self.multi_mad(self.core(input, attention_mask))
 
 

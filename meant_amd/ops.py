@@ -1517,6 +1517,59 @@ class _AttentionCore(torch.autograd.Function):
         return dqkv.view(ctx.in_shape), None, None, None, None, None, None, None
 
 
+class _AttentionCoreScoreDropout(torch.autograd.Function):
+    """_AttentionCore with dropout on the score matrix (meant/xPosAttention.py:59: after the causal fill and the padding term, before
+    the softmax).  The fused kernels never see a score matrix; this runs the materialised fp32 core (meant_attn_drop_fwd / _bwd): rotary
+    by meant_rotary_qk in front, its adjoint behind the backward.  No reference model sets the probability above zero."""
+
+    @staticmethod
+    def forward(ctx, qkv, tables, G, S, H, scale, causal, key_mask, drop_p, seed):
+        _need_gpu(qkv)
+        dt = _dt(qkv)
+        D3 = qkv.shape[-1]
+        D = D3 // 3
+        Dh = D // H
+        qa, qb, ka, kb = tables if tables is not None else (None, None, None, None)
+        R = qa.shape[1] if qa is not None else 0
+        q2 = qkv.reshape(G * S, D3)
+        if qa is not None:
+            q2 = q2.clone() if q2.data_ptr() == qkv.data_ptr() else q2
+            check(lib.meant_rotary_qk(_p(q2), G * S, S, H, Dh, R, _p(qa), _p(qb), _p(ka), _p(kb), 0, dt, _stream()), "rotary_qk")
+        else:
+            q2 = _c(q2)
+        o = torch.empty((G * S, D), device=qkv.device, dtype=qkv.dtype)
+        lse = torch.empty((G, H, S, 2), device=qkv.device, dtype=torch.float32)
+        km = _c(key_mask.float()) if key_mask is not None else None
+        wsb = lib.meant_attn_drop_ws(G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=qkv.device, dtype=torch.uint8)
+        check(lib.meant_attn_drop_fwd(_p(q2), _p(o), _p(lse), _p(km), G, S, H, Dh, float(scale), int(causal), float(drop_p), int(seed), dt,
+                                      _p(ws), wsb, _stream()), "attn_drop_fwd")
+        ctx.save_for_backward(q2, o, lse, km)
+        ctx.tables, ctx.meta, ctx.in_shape = tables, (G, S, H, Dh, float(scale), int(causal), float(drop_p), int(seed)), qkv.shape
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q2, o, lse, km = ctx.saved_tensors
+        G, S, H, Dh, scale, causal, drop_p, seed = ctx.meta
+        do2 = _c(do)
+        dt = _dt(do2)
+        dqkv = torch.empty_like(q2)
+        wsb = lib.meant_attn_drop_ws(G, S, H, Dh, dt)
+        ws = torch.empty(max(wsb, 16), device=do2.device, dtype=torch.uint8)
+        check(lib.meant_attn_drop_bwd(_p(q2), _p(o), _p(do2), _p(lse), _p(km), _p(dqkv), G, S, H, Dh, scale, causal, drop_p, seed, dt,
+                                      _p(ws), wsb, _stream()), "attn_drop_bwd")
+        if ctx.tables is not None:
+            qa, qb, ka, kb = ctx.tables
+            check(lib.meant_rotary_qk(_p(dqkv), G * S, S, H, Dh, qa.shape[1], _p(qa), _p(qb), _p(ka), _p(kb), 1, dt, _stream()), "rotary_qk^T")
+        return dqkv.view(ctx.in_shape), None, None, None, None, None, None, None, None, None
+
+
+def attention_core_score_dropout(qkv, G, S, H, scale, drop_p, seed, tables=None, causal=False, key_mask=None):
+    """attention_core with dropout(drop_p) on the score matrix; `seed` selects the mask (forward and backward share it)"""
+    return _AttentionCoreScoreDropout.apply(qkv, tables, int(G), int(S), int(H), float(scale), bool(causal), key_mask, float(drop_p), int(seed))
+
+
 def attention_core(qkv, G, S, H, scale, tables=None, causal=False, key_mask=None):
     """qkv: [G*S, 3*H*Dh] (or any shape with that many elements per row) -> o [G*S, H*Dh]"""
     return _AttentionCore.apply(qkv, tables, int(G), int(S), int(H), float(scale), bool(causal), key_mask)

@@ -326,6 +326,67 @@ def test_attention_with_learned_rotary_frequencies(M, O, dev, dtype, kind, G, S,
     assert_grad_close(gf, gr, tol["gelem"], "d freqs")
 
 
+def _hash_uniform_np(seed: int, idx):
+    """common.h:hash_uniform on the host: splitmix-style hash of (seed, index) -> [0, 1), in the kernel's float arithmetic"""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("G,S,H,d,p", [(3, 80, 2, 128, 0.25), (2, 200, 4, 256, 0.1), (2, 64, 2, 192, 0.5)])
+def test_xpos_attention_with_dropout_on_the_scores(M, O, dev, dtype, G, S, H, d, p):
+    """meant/xPosAttention.py:59: `scores = self.dropout(scores)` -- after the causal fill and the key-padding term, before the softmax
+    (p = 0 in every reference model).  The HIP path (materialised fp32 core) against the same arithmetic in eager fp32 on the host with
+    the SAME mask, rebuilt from the kernel's counter-based hash: a dropped score is 0 (a dropped FUTURE position becomes visible),
+    a kept one is divided by 1 - p.  Outputs, input gradient and every parameter gradient."""
+    ref = O.xPosAttention(H, d, O.RotaryTable(48, "lang", use_xpos=True))
+    hip = M.xPosAttention(H, d, M.RotaryEmbedding(dim=48, use_xpos=True), droput=p)
+    ref, hip = pair(ref, hip, 611, dev)
+    hip.train()
+    rs = np.random.RandomState(S + d)
+    x = t(rs.standard_normal((G, S, d)).astype("float32"))
+    dy = t(rs.standard_normal((G, S, d)).astype("float32"))
+    mask = torch.ones(G, S)
+    mask[0, S // 2:] = 0
+    # the module draws ONE seed per forward from torch's CPU generator (modules._seed)
+    torch.manual_seed(4242)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    idx = np.arange(G * H * S * S, dtype=np.uint64).reshape(G, H, S, S)
+    keep = torch.from_numpy(_hash_uniform_np(seed, idx) >= np.float32(p))
+    assert 0.5 * (1 - p) < keep.float().mean().item() < min(1.0, 1.5 * (1 - p))
+
+    def reference(xin):
+        Dh = d // H
+        q, k, v = (O._split_heads(f(xin), H) for f in (ref.q, ref.v, ref.k))          # the Linear called `v` makes the keys
+        cos, sin = ref.xPos.cos_sin(S)
+        zeta = ref.xPos.xpos_scale(S)
+        q, k = O.rotate_pairs(q, cos, sin, zeta), O.rotate_pairs(k, cos, sin, zeta ** -1)
+        sc = (q @ k.transpose(-1, -2)) / math.sqrt(Dh * H)
+        sc = sc.masked_fill(torch.ones(S, S, dtype=torch.bool).triu(1), float("-inf"))
+        sc = sc + (1 - mask[:, None, None, :]) * -1e9
+        sc = torch.where(keep, sc / (1 - p), torch.zeros_like(sc))                      # nn.Dropout on the scores, this mask
+        return ref.multi_mad(O._merge_heads(torch.softmax(sc, dim=-1) @ v))
+
+    xr = x.to(dtype).float().clone().requires_grad_()
+    yr = reference(xr)
+    yr.backward(dy.to(dtype).float())
+    torch.manual_seed(4242)
+    xh = x.to(dev).to(dtype).requires_grad_()
+    yh = hip(xh, mask.to(dev))
+    yh.backward(dy.to(dev).to(dtype))
+    tol = TOL[dtype]
+    assert_close(yh, yr, tol["out"] * (1 if dtype == torch.float32 else 4), "y")
+    assert_grad_close(xh.grad, xr.grad, tol["gelem"], "dx")
+    compare_param_grads(ref, hip, dtype, "xpos score dropout")
+    hip.eval()                                          # eval mode: no dropout, the fused path
+    ye = hip(xh.detach(), mask.to(dev))
+    assert_close(ye, ref(x.to(dtype).float(), mask), tol["out"] * (1 if dtype == torch.float32 else 4), "eval y")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("H,d", [(2, 128), (2, 192), (1, 128)], ids=["dh64", "dh96", "dh128"])
 def test_text_attention_padding_patterns(M, O, dev, dtype, H, d):
